@@ -1,0 +1,220 @@
+/* legged_hip.h -- C-ABI of liblegged_hip.so (MI355X / gfx950).
+ *
+ * The reference has no FFI boundary on this path: the hot loop sits behind two Python
+ * duck-typed interfaces:
+ *   B1  VecEnv            legged_gym/envs/base/base_task.py:60-81,101-122,
+ *                         legged_gym/envs/base/legged_robot.py:80-104
+ *   B3  gym tensor API    the ~45 gym.* calls of legged_robot.py (acquire_*_tensor :537-539,
+ *                         set_dof_actuation_force_tensor :92, simulate :93, refresh_* :96,111-112,
+ *                         set_*_tensor_indexed :428,452,461 ...)
+ * and, for the learner, rsl_rl's PPO/RolloutStorage/OnPolicyRunner (call sites
+ * legged_gym/utils/task_registry.py:148-155).  This header is the C-ABI introduced UNDERNEATH
+ * them; each entry cites the reference interface it replaces.  Plain pointers and PODs only,
+ * int return codes (0 = ok, negative = error, text via lg_last_error()), no exceptions cross the
+ * boundary.  One context = one HIP device + one stream; a context is not thread-safe.
+ *
+ * All device pointers handed in or out are HBM addresses on the context's device.
+ * The same structs (with host pointers) are used by the CPU oracle in oracle/ (lgo_* symbols),
+ * which is test infrastructure and never linked into this library.
+ */
+#ifndef LEGGED_HIP_H
+#define LEGGED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_MAX_DOF      16
+#define LG_MAX_BODIES   24
+#define LG_MAX_SPHERES  48
+#define LG_MAX_FEET      8
+#define LG_MAX_PEN      16
+#define LG_MAX_TERM      8
+#define LG_LSTM_NW     972   /* actuator net: see lg_cfg.lstm_w */
+#define LG_MAX_HIDDEN    4
+
+/* Reward terms in the order the reference sums them: alphabetical by name (class_to_dict walks
+ * dir(), legged_gym/utils/helpers.py:111-126); "termination" is applied last, after the optional
+ * positive clip (legged_robot.py:189-206). */
+enum lg_reward {
+    LG_REW_ACTION_RATE = 0, LG_REW_ANG_VEL_XY, LG_REW_BASE_HEIGHT, LG_REW_COLLISION, LG_REW_DOF_ACC,
+    LG_REW_DOF_POS_LIMITS, LG_REW_DOF_VEL, LG_REW_DOF_VEL_LIMITS, LG_REW_FEET_AIR_TIME,
+    LG_REW_FEET_CONTACT_FORCES, LG_REW_LIN_VEL_Z, LG_REW_NO_FLY, LG_REW_ORIENTATION, LG_REW_STAND_STILL,
+    LG_REW_STUMBLE, LG_REW_TERMINATION, LG_REW_TORQUE_LIMITS, LG_REW_TORQUES, LG_REW_TRACKING_ANG_VEL,
+    LG_REW_TRACKING_LIN_VEL, LG_NUM_REWARDS
+};
+
+/* Per-env random-draw slots.  In normal operation slot s of env e at step k is
+ * Philox4x32-10(key = seed, counter = (global env id, k, s / 4, 0))[s % 4] >> 8 scaled to [0,1);
+ * with lg_inject_uniforms() the value is read from the injected (N, K) buffer instead (parity
+ * tests replay the reference's torch.rand draws this way).  K = LG_SLOT_NOISE(A) + num_obs. */
+#define LG_SLOT_CMD        0   /* 3: callback command resample x, y, yaw|heading (legged_robot.py:365-387) */
+#define LG_SLOT_PUSH       3   /* 2: push velocity xy (:456-461) */
+#define LG_SLOT_LEVEL      5   /* 1: terrain level when the curriculum wraps (:479-483) */
+#define LG_SLOT_DOF        6   /* A: reset joint position factors (:415-430) */
+#define LG_SLOT_XY(A)     (6 + (A))        /* 2: reset xy offset on terrain (:443-446) */
+#define LG_SLOT_VEL(A)    (8 + (A))        /* 6: reset base twist (:451) */
+#define LG_SLOT_RCMD(A)   (14 + (A))       /* 3: command resample of reset envs */
+#define LG_SLOT_NOISE(A)  (17 + (A))       /* num_obs: observation noise (:224-226) */
+
+/* Collapsed articulated model: what gym.load_asset + get_asset_* give the reference
+ * (legged_robot.py:693-724).  Produced by legged_gym_dev_amd/model/robot_model.py.
+ * Dynamics links: index 0 = floating base, 1+d = link moved by DOF d.  Topology: L serial
+ * chains of J revolute joints, DOF index = leg * J + joint. */
+typedef struct lg_model {
+    int32_t num_bodies, num_dofs, num_legs, joints_per_leg, num_spheres, _pad0[3];
+    float mass[LG_MAX_DOF + 1];
+    float com[LG_MAX_DOF + 1][3];         /* link frame */
+    float inertia[LG_MAX_DOF + 1][9];     /* about com, link axes, row major */
+    float R_pj[LG_MAX_DOF][9];            /* joint frame axes in the parent link frame (columns) */
+    float p_pj[LG_MAX_DOF][3];
+    float axis[LG_MAX_DOF][3];            /* unit, joint frame */
+    float q_lower[LG_MAX_DOF], q_upper[LG_MAX_DOF];   /* equal -> no position limit */
+    float effort[LG_MAX_DOF], vel_limit[LG_MAX_DOF], joint_damping[LG_MAX_DOF];
+    int32_t body_dyn[LG_MAX_BODIES];      /* body -> dynamics link (-1 base, else DOF) */
+    int32_t sph_link[LG_MAX_SPHERES];     /* -1 base, else DOF */
+    int32_t sph_body[LG_MAX_SPHERES];     /* row of the net-contact-force tensor it reports to */
+    float sph_center[LG_MAX_SPHERES][3];  /* dynamics-link frame */
+    float sph_radius[LG_MAX_SPHERES];
+} lg_model;
+
+/* Flattened LeggedRobotCfg (+ what _parse_cfg/_init_buffers derive from it,
+ * legged_robot.py:533-603,819-837). */
+typedef struct lg_cfg {
+    int32_t num_envs, num_obs, num_actions, num_bodies;
+    int32_t num_feet, num_pen, num_term, num_height_points;
+    int32_t feet_idx[LG_MAX_FEET], pen_idx[LG_MAX_PEN], term_idx[LG_MAX_TERM];
+    int32_t decimation, control_type /*0 P,1 V,2 T*/, use_actuator_net, heading_command;
+    int32_t max_episode_length, resample_steps, push_interval, push_robots;
+    int32_t add_noise, measure_heights, only_positive_rewards, send_timeouts;
+    int32_t terrain_type /*0 plane, 1 height samples*/, curriculum, custom_origins, max_terrain_level;
+    int32_t hf_rows, hf_cols, terrain_num_cols, phys_substeps;
+    int32_t env_offset, total_envs;       /* this shard's first global env id / envs over all ranks */
+    int32_t solver_iterations, _pad1;
+    uint64_t seed;
+    float sim_dt, dt, action_scale, clip_actions, clip_obs, max_push_vel, episode_length_s, _pad2;
+    float cmd_lo[4], cmd_hi[4];           /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading */
+    float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+    float tracking_sigma, soft_dof_vel_limit, soft_torque_limit, base_height_target, max_contact_force;
+    float hf_hscale, hf_vscale, border_size, terrain_env_length;
+    float rew_scale[LG_NUM_REWARDS];      /* already multiplied by dt; 0 = term inactive */
+    float base_init_state[13];
+    float default_dof_pos[LG_MAX_DOF], p_gains[LG_MAX_DOF], d_gains[LG_MAX_DOF];
+    float dof_pos_limits[LG_MAX_DOF][2];  /* soft limits (legged_robot.py:313-327) */
+    float dof_vel_limits[LG_MAX_DOF], torque_limits[LG_MAX_DOF];
+    float gravity[3], ground_friction;    /* ground mu; combined with the env's mu by averaging */
+    float contact_offset, max_depenetration_velocity, contact_erp, _pad3;
+    float lstm_w[LG_LSTM_NW];             /* in_scale2 out_scale1 | w_ih0 64 w_hh0 256 b_ih0 32 b_hh0 32 |
+                                             w_ih1 256 w_hh1 256 b_ih1 32 b_hh1 32 | lin_w 8 lin_b 1 */
+    const float *noise_vec;               /* host, num_obs   (legged_robot.py:507-530) */
+    const float *height_points;           /* host, num_height_points x 2, x-major grid (:861-875) */
+    const float *terrain_origins;         /* host, rows(levels) x terrain_num_cols x 3, or NULL */
+} lg_cfg;
+
+/* State tensors.  Layouts are the reference's: root (N,13) =
+ * [pos3, quat xyzw, lin vel3, ang vel3] world frame; dof_state (N,A,2) = [q, qdot] interleaved;
+ * contact (N,B,3) world N; episode_sums is (LG_NUM_REWARDS, N) so each term is a contiguous (N,). */
+typedef struct lg_buffers {
+    float *root_states, *dof_state, *contact_forces, *torques, *actions;
+    float *obs, *rew;
+    uint8_t *reset, *time_out;
+    int64_t *episode_length;
+    float *commands, *last_actions, *last_dof_vel, *last_root_vel, *feet_air_time;
+    uint8_t *last_contacts;
+    float *episode_sums, *base_lin_vel, *base_ang_vel, *projected_gravity, *measured_heights;
+    float *env_origins;
+    int64_t *terrain_levels, *terrain_types;
+    float *lstm_h, *lstm_c;               /* (2, N*A, 8) each, anymal.py:62-69 */
+    float *friction, *base_mass_delta;    /* per-env randomised constants (legged_robot.py:259-341) */
+    /* extras: filled by the step's finalize pass; episode means only change on steps where at
+     * least one env resets, time_outs likewise (the reference's stale-mask quirk, :156-157,186-187) */
+    float *extras_episode;                /* LG_NUM_REWARDS */
+    float *extras_terrain_level;          /* 1 */
+    uint8_t *extras_time_outs;            /* N */
+    int32_t *n_reset;                     /* 1: envs reset by the last step */
+    float *inject_uniforms;               /* (N, K) or unused */
+    int64_t *inject_levels;               /* N */
+} lg_buffers;
+
+typedef struct lg_ctx lg_ctx;
+
+const char *lg_last_error(void);
+int lg_version(void);
+
+/* Replaces create_sim/_create_envs/prepare_sim/acquire_*_tensor (base_task.py:84-85,
+ * legged_robot.py:228-245,537-539).  height_samples: host int16 (hf_rows x hf_cols) or NULL. */
+int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_samples, lg_ctx **out);
+int lg_destroy(lg_ctx *ctx);
+int lg_get_buffers(lg_ctx *ctx, lg_buffers *out);
+/* stream = hipStream_t; all later calls enqueue on it (the caller's torch stream). */
+int lg_set_stream(lg_ctx *ctx, void *stream);
+/* counterpart of env.common_step_counter (legged_robot.py:115); set by tests/resume. */
+int lg_set_step_counter(lg_ctx *ctx, int64_t counter);
+int64_t lg_get_step_counter(lg_ctx *ctx);
+int lg_set_init_done(lg_ctx *ctx, int init_done);     /* legged_robot.py:472-474 */
+/* enable (1) / disable (0) replay of buffers.inject_uniforms / inject_levels. */
+int lg_inject_uniforms(lg_ctx *ctx, int enable);
+
+/* LeggedRobot.step (legged_robot.py:80-104): clip actions, decimation x {torque law, physics
+ * substep}, post_physics_step, clip observations.  actions: device (N, A) f32. */
+int lg_step(lg_ctx *ctx, const float *actions);
+/* Finer-grained entry points (tests, teacher forcing): */
+int lg_set_actions(lg_ctx *ctx, const float *actions);         /* :86-87 */
+int lg_compute_torques(lg_ctx *ctx);                           /* :91 (PD :389-413 / LSTM anymal.py:71-81) */
+int lg_simulate(lg_ctx *ctx);                                  /* :92-96, one sim_dt of physics */
+int lg_post_physics_step(lg_ctx *ctx);                         /* :106-137 + obs clip :100-103 */
+int lg_reset_all(lg_ctx *ctx);                                 /* reset_idx(arange(N)), base_task.py:113 */
+
+/* ------------------------------------------------------------------ PPO (rsl_rl v1.0.2 semantics,
+ * SURVEY.md Appendix B; call sites task_registry.py:148-155, scripts/train.py:44) */
+typedef struct lg_ppo_cfg {
+    int32_t num_envs, num_obs, num_critic_obs, num_actions;
+    int32_t num_hidden, actor_hidden[LG_MAX_HIDDEN], critic_hidden[LG_MAX_HIDDEN];
+    int32_t activation /*0 elu (others rejected)*/, num_steps, num_epochs, num_mini_batches;
+    int32_t adaptive_schedule, use_clipped_value_loss, world_size, _pad;
+    uint64_t seed;
+    float init_noise_std, value_loss_coef, clip_param, entropy_coef, learning_rate;
+    float gamma, lam, desired_kl, max_grad_norm, _padf;
+} lg_ppo_cfg;
+
+typedef struct lg_ppo_buffers {
+    float *params, *grads, *adam_m, *adam_v;      /* flat, num_params (+ tail, see num_reduce) */
+    float *obs, *critic_obs, *actions, *rewards, *values, *returns, *advantages, *log_prob, *mu, *sigma;
+    uint8_t *dones;                                /* storage, time major (T, N, .) */
+    float *act_actions, *act_values, *act_log_prob, *act_mu;   /* outputs of the last act() */
+    float *stats;                                  /* [lr, kl, value_loss, surrogate_loss, mean_std, n_updates, adv_mean, adv_std] */
+    float *noise;                                  /* (N, A) injected N(0,1) for act(), or unused */
+    int32_t *perm;                                 /* minibatch permutation (T*N) */
+    float *adv_partial;                            /* [sum, sumsq, count] for cross-rank normalisation */
+    int64_t num_params, num_reduce;                /* floats to all-reduce per optimiser step */
+} lg_ppo_buffers;
+
+typedef struct lg_ppo lg_ppo;
+
+int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out);
+int lg_ppo_destroy(lg_ppo *p);
+int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out);
+int lg_ppo_set_stream(lg_ppo *p, void *stream);
+int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_entries); /* returns #tensors */
+int lg_ppo_inject_noise(lg_ppo *p, int enable);
+/* PPO.act: actor+critic forward, sample, log-prob; stores the transition at the current step. */
+int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs);
+/* PPO.process_env_step: reward += gamma * V * time_outs; store reward/done; advance step. */
+int lg_ppo_process_env_step(lg_ppo *p, const float *rew, const uint8_t *dones, const uint8_t *time_outs);
+/* PPO.compute_returns: bootstrap value, GAE reverse scan, local advantage sums. */
+int lg_ppo_compute_returns(lg_ppo *p, const float *last_critic_obs);
+int lg_ppo_normalize_advantages(lg_ppo *p);        /* after adv_partial was (all-)reduced */
+/* PPO.update split so the caller can all-reduce grads between the two halves: */
+int lg_ppo_begin_update(lg_ppo *p);                /* new permutation, zero loss stats */
+int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb);   /* fwd, loss, bwd -> grads (+KL tail) */
+int lg_ppo_minibatch_step(lg_ppo *p);              /* KL-adaptive lr, clip_grad_norm, Adam */
+int lg_ppo_end_update(lg_ppo *p);                  /* finalise mean losses, clear storage */
+/* actor mean only (act_inference) for play/eval */
+int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEGGED_HIP_H */

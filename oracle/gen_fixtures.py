@@ -418,6 +418,7 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
         torch.jit.load = orig_jit_load
 
     log = _DrawLog()
+    log.install()
     for meth, tag in (("_resample_commands", "resample"), ("_push_robots", "push"),
                       ("_reset_dofs", "reset_dof"), ("_reset_root_states", "reset_root"),
                       ("_update_terrain_curriculum", "curric"), ("compute_observations", "obs")):
@@ -438,7 +439,7 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
     S = slot_layout(A, O)
     rew_names = list(env.reward_scales.keys())          # alphabetical, zero scales dropped, x dt
     F = len(env.feet_indices)
-    use_lstm = hasattr(env, "sea_hidden_state")
+    use_lstm = hasattr(env, "sea_hidden_state") and bool(cfg.control.use_actuator_network)
     out = {"meta_json": None}
     const = {
         "feet_indices": env.feet_indices.numpy(), "penalised_contact_indices": env.penalised_contact_indices.numpy(),
@@ -575,6 +576,7 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
                 st["contact_forces"].view(N, B, 3)[:] = cf
             calls["n"] += 1
         st["simulate_hook"] = hook
+        out[f"s{t}_pre_episode_length_buf"] = env.episode_length_buf.numpy().copy()
         st["applied_torques"].clear()
         log.entries.clear()
         log.active = True

@@ -1,0 +1,208 @@
+"""Shared helpers for the parity tests: rebuild the fixture's configuration with THIS repo's
+config classes, replay a golden fixture (tests/golden/*.npz, made by oracle/gen_fixtures.py from
+the reference's own Python) through an env handle (CPU oracle or HIP), and compare."""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from legged_gym_dev_amd import capi  # noqa: E402
+from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float  # noqa: E402
+from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FIXTURES = ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_allrewards", "anymal_c_pd_V", "anymal_c_pd_T"]
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    return z, meta
+
+
+def _small_terrain(cfg):
+    cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = 3, 5, 5
+    cfg.terrain.max_init_terrain_level = 2
+
+
+def make_cfg(name):
+    """Mirror of the per-case overrides in oracle/gen_fixtures.py main(), on our config classes."""
+    from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from legged_gym_dev_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
+    from legged_gym_dev_amd.envs.cassie.cassie_config import CassieRoughCfg
+    if name == "anymal_c_flat":
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 64
+    elif name == "anymal_c_rough":
+        cfg = AnymalCRoughCfg()
+        cfg.env.num_envs = 64
+        _small_terrain(cfg)
+    elif name == "cassie":
+        cfg = CassieRoughCfg()
+        cfg.env.num_envs = 64
+        _small_terrain(cfg)
+    elif name == "anymal_c_allrewards":
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 64
+        cfg.control.use_actuator_network = False
+        cfg.commands.heading_command = True
+        cfg.commands.ranges.lin_vel_x = [-1.0, 1.0]
+        cfg.commands.ranges.lin_vel_y = [-1.0, 1.0]
+        cfg.commands.ranges.heading = [-3.14, 3.14]
+        cfg.rewards.only_positive_rewards = False
+        cfg.rewards.soft_dof_vel_limit = 0.5
+        cfg.rewards.soft_torque_limit = 0.5
+        for k, v in dict(termination=-3.0, tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_vel_z=-2.0,
+                         ang_vel_xy=-0.05, orientation=-0.5, torques=-1e-5, dof_vel=-1e-3, dof_acc=-2.5e-7,
+                         base_height=-1.0, feet_air_time=1.0, collision=-1.0, stumble=-0.5, action_rate=-0.01,
+                         stand_still=-0.1, dof_pos_limits=-1.0, dof_vel_limits=-0.3, torque_limits=-0.2,
+                         feet_contact_forces=-0.01).items():
+            setattr(cfg.rewards.scales, k, v)
+        cfg.terrain.measure_heights = True
+        cfg.env.num_observations = 235
+    elif name.startswith("anymal_c_pd_"):
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 32
+        cfg.control.use_actuator_network = False
+        cfg.control.control_type = name[-1]
+    else:
+        raise KeyError(name)
+    return cfg
+
+
+class FixtureTerrain:
+    """Terrain stand-in carrying the fixture's height samples / tile origins."""
+
+    def __init__(self, z, meta, cfg):
+        hs = z["const_height_samples"]
+        self.heightsamples = self.height_field_raw = hs
+        self.tot_rows, self.tot_cols = hs.shape
+        self.env_length = meta["terrain_env_length"]
+        self.env_origins = z["const_terrain_origins"]
+        self.cfg = cfg.terrain
+
+
+def make_setup(name, z, meta):
+    cfg = make_cfg(name)
+    cm = compile_model(resolve_model("", meta["robot"]))
+    terrain = FixtureTerrain(z, meta, cfg) if "const_height_samples" in z.files else None
+    return EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), terrain=terrain, seed=1), cfg
+
+
+def check_setup_against_fixture(setup, z, meta):
+    """Host logic pinned against what the reference derived (feet indices, gains, limits, ...)."""
+    assert setup.feet_indices == z["const_feet_indices"].tolist()
+    assert setup.penalised_contact_indices == z["const_penalised_contact_indices"].tolist()
+    assert setup.termination_contact_indices == z["const_termination_contact_indices"].tolist()
+    np.testing.assert_array_equal(setup.default_dof_pos, z["const_default_dof_pos"])
+    np.testing.assert_array_equal(setup.p_gains, z["const_p_gains"])
+    np.testing.assert_array_equal(setup.d_gains, z["const_d_gains"])
+    np.testing.assert_array_equal(setup.dof_pos_limits, z["const_dof_pos_limits"])
+    np.testing.assert_array_equal(setup.dof_vel_limits, z["const_dof_vel_limits"])
+    np.testing.assert_array_equal(setup.torque_limits, z["const_torque_limits"])
+    np.testing.assert_array_equal(setup.noise_scale_vec, z["const_noise_scale_vec"])
+    assert list(setup.reward_scales.keys()) == meta["reward_names"]
+    np.testing.assert_array_equal(np.array([setup.reward_scales[k] for k in meta["reward_names"]]),
+                                  z["const_reward_scales"])
+    assert setup.dt == meta["dt"]
+    assert setup.max_episode_length == meta["max_episode_length"]
+    assert setup.push_time == meta["push_time"]
+    assert int(setup.cfg.commands.resampling_time / setup.dt) == meta["resample_steps"]
+    if setup.measure_heights:
+        np.testing.assert_array_equal(setup.height_points, z["const_height_points"][:, :2])
+
+
+def load_state(env, z, prefix, meta):
+    """Install a fixture snapshot (init_ or sK_post_) into the env handle's buffers."""
+    names = meta["reward_names"]
+    env.set("root_states", z[prefix + "root_states"])
+    env.set("dof_state", z[prefix + "dof_state"])
+    env.set("commands", z[prefix + "commands"])
+    env.set("last_actions", z[prefix + "last_actions"])
+    env.set("last_dof_vel", z[prefix + "last_dof_vel"])
+    env.set("last_root_vel", z[prefix + "last_root_vel"])
+    env.set("feet_air_time", z[prefix + "feet_air_time"])
+    env.set("last_contacts", z[prefix + "last_contacts"].astype(np.uint8))
+    env.set("episode_length", z[prefix + "episode_length_buf"])
+    es = np.zeros((capi.NUM_REWARDS, meta["num_envs"]), np.float32)
+    for k, n in enumerate(names):
+        es[capi.REWARD_NAMES.index(n)] = z[prefix + "episode_sums"][:, k]
+    env.set("episode_sums", es)
+    env.set("env_origins", z[prefix + "env_origins"])
+    if prefix + "terrain_levels" in z.files:
+        env.set("terrain_levels", z[prefix + "terrain_levels"])
+        env.set("terrain_types", z["const_terrain_types"])
+    if meta["use_lstm"]:
+        env.set("lstm_h", z[prefix + "lstm_h"])
+        env.set("lstm_c", z[prefix + "lstm_c"])
+
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def replay_fixture(env, z, meta, torque_tol=None, report=None):
+    """Teacher-forced replay of every recorded step; asserts parity with the reference outputs.
+
+    Bit-exact: reset / time_out masks, episode lengths, terrain levels, last_contacts, reset count.
+    fp32 within TOL (rtol=atol=2e-5; torques from the actuator net 1e-4 abs): everything else."""
+    N, A = meta["num_envs"], meta["num_dofs"]
+    names = meta["reward_names"]
+    ridx = [capi.REWARD_NAMES.index(n) for n in names]
+    ttol = torque_tol or dict(rtol=1e-4, atol=2e-4)
+    load_state(env, z, "init_", meta)
+    env.set_step_counter(int(z["init_common_step_counter"]))
+    env.set_init_done(1)
+    env.inject(1)
+    dec = z["s0_sub_dof"].shape[0]
+    for t in range(meta["n_steps"]):
+        p = f"s{t}_"
+        env.set("episode_length", z[p + "pre_episode_length_buf"])   # generator edits it before step 2
+        env.set_actions(z[p + "actions"])
+        for k in range(dec):
+            env.call("compute_torques")
+            np.testing.assert_allclose(env.get("torques"), z[p + "sub_torques"][k], err_msg=f"{p}substep{k} torques", **ttol)
+            env.set("dof_state", z[p + "sub_dof"][k])           # teacher forcing (physics not in fixture)
+        env.set("root_states", z[p + "new_root"])
+        env.set("contact_forces", z[p + "contact_forces"])
+        U = np.nan_to_num(z[p + "uniforms"], nan=0.5)
+        env.set("inject_uniforms", U)
+        env.set("inject_levels", np.maximum(z[p + "inj_level"], 0))
+        env.call("post_physics_step")
+        env.sync()
+        # ---- integer / mask outputs: bit exact
+        np.testing.assert_array_equal(env.get("reset").astype(bool), z[p + "reset"].astype(bool), err_msg=p + "reset")
+        np.testing.assert_array_equal(env.get("time_out").astype(bool), z[p + "time_out"], err_msg=p + "time_out")
+        np.testing.assert_array_equal(env.get("episode_length"), z[p + "post_episode_length_buf"], err_msg=p + "ep_len")
+        np.testing.assert_array_equal(env.get("last_contacts").astype(bool), z[p + "post_last_contacts"], err_msg=p + "last_contacts")
+        assert int(env.get("n_reset")[0]) == int(z[p + "n_reset"]), p + "n_reset"
+        if p + "post_terrain_levels" in z.files:
+            np.testing.assert_array_equal(env.get("terrain_levels"), z[p + "post_terrain_levels"], err_msg=p + "levels")
+        np.testing.assert_array_equal(env.get("extras_time_outs").astype(bool), z[p + "extras_time_outs"],
+                                      err_msg=p + "extras time_outs (stale-mask quirk)")
+        # ---- fp32 outputs
+        for key, ref in (("obs", z[p + "obs"]), ("rew", z[p + "rew"]), ("root_states", z[p + "post_root_states"]),
+                         ("dof_state", z[p + "post_dof_state"]), ("commands", z[p + "post_commands"]),
+                         ("last_actions", z[p + "post_last_actions"]), ("last_dof_vel", z[p + "post_last_dof_vel"]),
+                         ("last_root_vel", z[p + "post_last_root_vel"]), ("feet_air_time", z[p + "post_feet_air_time"]),
+                         ("env_origins", z[p + "post_env_origins"])):
+            np.testing.assert_allclose(env.get(key), ref, err_msg=p + key, **TOL)
+        if z[p + "measured_heights"].shape[1]:
+            np.testing.assert_allclose(env.get("measured_heights"), z[p + "measured_heights"], err_msg=p + "heights", **TOL)
+        es = env.get("episode_sums")[ridx].T if ridx else np.zeros((N, 0), np.float32)
+        np.testing.assert_allclose(es, z[p + "post_episode_sums"], err_msg=p + "episode_sums", **TOL)
+        if int(z[p + "n_reset"]) > 0 and ridx:
+            np.testing.assert_allclose(env.get("extras_episode")[ridx], z[p + "extras_episode"], rtol=1e-4, atol=1e-5,
+                                       err_msg=p + "extras episode means")
+            if meta["curriculum"]:
+                np.testing.assert_allclose(env.get("extras_terrain_level")[0], z[p + "extras_terrain_level"], rtol=1e-5)
+        if meta["use_lstm"]:
+            np.testing.assert_allclose(env.get("lstm_h"), z[p + "post_lstm_h"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_h")
+            np.testing.assert_allclose(env.get("lstm_c"), z[p + "post_lstm_c"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_c")
+        if report is not None:
+            report.append((t, float(np.abs(env.get("obs") - z[p + "obs"]).max())))
