@@ -1,0 +1,234 @@
+"""Physics oracle (oracle/lgo_physics.cpp) validated by invariants.
+
+PhysX is closed and absent, so parity of the physics step with the reference is UNPINNED
+(SURVEY.md §8(c)); what pins our own specification is physics itself:
+  * free dynamics == float64 mass-matrix dynamics  M(q) nu_dot + h(q, nu) = tau  built from link
+    Jacobians in the world frame (an independent formulation: no articulated-body recursion),
+  * momentum conservation without gravity,
+  * static stance: sum of vertical contact forces == total weight, base stays put.
+"""
+import numpy as np
+import pytest
+
+from tests import harness
+from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+
+
+def _cfg(robot, n=8, gravity=True):
+    from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from legged_gym_dev_amd.envs.cassie.cassie_config import CassieRoughCfg
+    if robot == "anymal_c":
+        cfg = AnymalCFlatCfg()
+        cfg.control.use_actuator_network = False
+    else:
+        cfg = CassieRoughCfg()
+        cfg.terrain.mesh_type = "plane"
+        cfg.terrain.measure_heights = False
+        cfg.env.num_observations = 48
+    cfg.env.num_envs = n
+    cfg.control.control_type = "T"
+    cfg.control.action_scale = 1.0
+    if not gravity:
+        cfg.sim.gravity = [0.0, 0.0, 0.0]
+    return cfg
+
+
+def _make(robot, oracle_built, n=8, gravity=True, cfg=None):
+    cfg = cfg or _cfg(robot, n, gravity)
+    cm = compile_model(resolve_model("", robot))
+    setup = EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt))
+    return oracle_built.OracleEnv(setup), cm, cfg
+
+
+def _quat_mat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _rot(a, th):
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _kin(cm, x, Rb, q):
+    """World pose of every dynamics link + joint axes/origins."""
+    A, J = cm["num_dofs"], cm["joints_per_leg"]
+    R, p, ax, po = [Rb], [x], [], []
+    for d in range(A):
+        pl = 0 if d % J == 0 else d
+        Rj = R[pl] @ cm["R_pj"][d].astype(np.float64)
+        pj = p[pl] + R[pl] @ cm["p_pj"][d].astype(np.float64)
+        a = cm["axis"][d].astype(np.float64)
+        ax.append(Rj @ a)
+        po.append(pj)
+        R.append(Rj @ _rot(a, q[d]))
+        p.append(pj)
+    return R, p, ax, po
+
+
+def _jacobians(cm, x, Rb, q):
+    A, J = cm["num_dofs"], cm["joints_per_leg"]
+    R, p, ax, po = _kin(cm, x, Rb, q)
+    out = []
+    for l in range(A + 1):
+        c = p[l] + R[l] @ cm["com"][l].astype(np.float64)
+        Jv, Jw = np.zeros((3, 6 + A)), np.zeros((3, 6 + A))
+        Jv[:, :3] = np.eye(3)
+        r = c - x
+        Jv[:, 3:6] = -np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+        Jw[:, 3:6] = np.eye(3)
+        if l > 0:
+            leg = (l - 1) // J
+            for d in range(leg * J, l):
+                Jv[:, 6 + d] = np.cross(ax[d], c - po[d])
+                Jw[:, 6 + d] = ax[d]
+        Iw = R[l] @ cm["inertia"][l].astype(np.float64) @ R[l].T
+        out.append((float(cm["mass"][l]), Jv, Jw, Iw))
+    return out
+
+
+def _advance(x, Rb, q, nu, eps):
+    w = nu[3:6]
+    th = np.linalg.norm(w) * eps
+    Rn = (_rot(w / np.linalg.norm(w), th) if th != 0 else np.eye(3)) @ Rb
+    return x + eps * nu[:3], Rn, q + eps * nu[6:]
+
+
+def mass_matrix_dynamics(cm, x, quat, q, v_w, w_w, qd, tau, g):
+    """nu_dot for nu = [v_w, w_w, qd] from M nu_dot + h = tau_gen (float64)."""
+    A = cm["num_dofs"]
+    Rb = _quat_mat(quat)
+    nu = np.concatenate([v_w, w_w, qd])
+    J0 = _jacobians(cm, x, Rb, q)
+    eps = 1e-6
+    Jp = _jacobians(cm, *_advance(x, Rb, q, nu, eps))
+    Jm = _jacobians(cm, *_advance(x, Rb, q, nu, -eps))
+    M = np.zeros((6 + A, 6 + A))
+    h = np.zeros(6 + A)
+    for (m, Jv, Jw, Iw), (_, Jvp, Jwp, _), (_, Jvm, Jwm, _) in zip(J0, Jp, Jm):
+        M += m * Jv.T @ Jv + Jw.T @ Iw @ Jw
+        dJv = (Jvp - Jvm) / (2 * eps) @ nu
+        dJw = (Jwp - Jwm) / (2 * eps) @ nu
+        w = Jw @ nu
+        h += Jv.T @ (m * dJv - m * g) + Jw.T @ (Iw @ dJw + np.cross(w, Iw @ w))
+    tg = np.concatenate([np.zeros(6), tau])
+    return np.linalg.solve(M, tg - h), M
+
+
+def _random_state(env, cm, rng, n, z=5.0):
+    A = cm["num_dofs"]
+    root = np.zeros((n, 13), np.float32)
+    root[:, 2] = z
+    qn = rng.normal(size=(n, 4))
+    root[:, 3:7] = qn / np.linalg.norm(qn, axis=1, keepdims=True)
+    root[:, 7:13] = rng.uniform(-1.5, 1.5, (n, 6))
+    dof = np.zeros((n, A, 2), np.float32)
+    dof[..., 0] = env.setup.default_dof_pos + rng.uniform(-0.5, 0.5, (n, A))
+    dof[..., 1] = rng.uniform(-4, 4, (n, A))
+    env.set("root_states", root)
+    env.set("dof_state", dof)
+    return root, dof
+
+
+@pytest.mark.parametrize("robot", ["anymal_c", "cassie"])
+def test_free_dynamics_match_mass_matrix_formulation(robot, oracle_built):
+    env, cm, cfg = _make(robot, oracle_built)
+    try:
+        rng = np.random.default_rng(0)
+        n, A = 8, cm["num_dofs"]
+        root, dof = _random_state(env, cm, rng, n)
+        tau = rng.uniform(-30, 30, (n, A)).astype(np.float32)
+        env.set("torques", tau)
+        env.call("simulate")
+        r1, d1 = env.get("root_states"), env.get("dof_state")
+        dt = env.setup.sim_dt
+        g = np.array(cfg.sim.gravity, np.float64)
+        for i in range(n):
+            nud, _ = mass_matrix_dynamics(cm, root[i, :3].astype(np.float64), root[i, 3:7].astype(np.float64),
+                                          dof[i, :, 0].astype(np.float64), root[i, 7:10].astype(np.float64),
+                                          root[i, 10:13].astype(np.float64), dof[i, :, 1].astype(np.float64),
+                                          tau[i].astype(np.float64), g)
+            acc_lin = (r1[i, 7:10] - root[i, 7:10]) / dt
+            acc_ang = (r1[i, 10:13] - root[i, 10:13]) / dt
+            qdd = (d1[i, :, 1] - dof[i, :, 1]) / dt
+            scale = max(1.0, np.abs(nud).max())
+            np.testing.assert_allclose(acc_lin, nud[:3], atol=2e-3 * scale)
+            np.testing.assert_allclose(acc_ang, nud[3:6], atol=2e-3 * scale)
+            np.testing.assert_allclose(qdd, nud[6:], atol=2e-3 * scale)
+            assert np.all(env.get("contact_forces")[i] == 0)
+    finally:
+        env.close()
+
+
+def _momentum(cm, root, dof):
+    Rb = _quat_mat(root[3:7].astype(np.float64))
+    nu = np.concatenate([root[7:10], root[10:13], dof[:, 1]]).astype(np.float64)
+    P, L = np.zeros(3), np.zeros(3)
+    R, p, _, _ = _kin(cm, root[:3].astype(np.float64), Rb, dof[:, 0].astype(np.float64))
+    for l, (m, Jv, Jw, Iw) in enumerate(_jacobians(cm, root[:3].astype(np.float64), Rb, dof[:, 0].astype(np.float64))):
+        c = p[l] + R[l] @ cm["com"][l].astype(np.float64)
+        v, w = Jv @ nu, Jw @ nu
+        P += m * v
+        L += np.cross(c, m * v) + Iw @ w
+    return P, L
+
+
+def test_momentum_conserved_without_gravity(oracle_built):
+    env, cm, cfg = _make("anymal_c", oracle_built, n=4, gravity=False)
+    try:
+        rng = np.random.default_rng(1)
+        root, dof = _random_state(env, cm, rng, 4)
+        dof[..., 1] *= 0.25                     # stay clear of the 20 rad/s joint-velocity clamp
+        env.set("dof_state", dof)
+        env.set("torques", rng.uniform(-1, 1, (4, 12)).astype(np.float32))     # internal torques only
+        P0 = [_momentum(cm, root[i], dof[i]) for i in range(4)]
+        for _ in range(40):
+            env.call("simulate")
+        r, d = env.get("root_states"), env.get("dof_state")
+        for i in range(4):
+            P1, L1 = _momentum(cm, r[i], d[i])
+            np.testing.assert_allclose(P1, P0[i][0], atol=0.02 * 52)       # 2 cm/s of the 52 kg robot
+            np.testing.assert_allclose(L1, P0[i][1], atol=0.05 * max(1.0, np.abs(P0[i][1]).max()))
+    finally:
+        env.close()
+
+
+@pytest.mark.parametrize("robot,height", [("anymal_c", 0.56), ("cassie", 0.95)])
+def test_static_stance_supports_weight(robot, height, oracle_built):
+    cfg = _cfg(robot, n=4)
+    cfg.control.control_type = "P"
+    cfg.control.action_scale = 0.5
+    env, cm, cfg = _make(robot, oracle_built, cfg=cfg)
+    try:
+        n, A = 4, cm["num_dofs"]
+        root = np.zeros((n, 13), np.float32)
+        root[:, 2] = height
+        root[:, 6] = 1.0
+        dof = np.zeros((n, A, 2), np.float32)
+        dof[..., 0] = env.setup.default_dof_pos
+        env.set("root_states", root)
+        env.set("dof_state", dof)
+        env.set("friction", np.ones(n, np.float32))
+        env.set_actions(np.zeros((n, A), np.float32))
+        fz = []
+        for k in range(300):
+            env.call("compute_torques")
+            env.call("simulate")
+            fz.append(env.get("contact_forces")[:, :, 2].sum(1))
+        r = env.get("root_states")
+        assert np.all(np.isfinite(r))
+        weight = float(cm["mass"].sum()) * 9.81
+        if robot == "anymal_c":      # statically stable quadruped stance
+            np.testing.assert_allclose(np.mean(fz[-50:], 0), weight, rtol=0.03)
+            assert np.all(np.abs(r[:, 2] - r[0, 2]) < 1e-3)
+            assert np.all(r[:, 2] > 0.35) and np.all(r[:, 2] < 0.62)
+            assert np.all(np.abs(r[:, 7:13]) < 0.05)
+            feet = env.get("contact_forces")[:, env.setup.feet_indices, 2]
+            assert np.all(feet > 0.1 * weight / 4)
+        else:                        # a PD-held biped is not statically stable: only sanity
+            assert np.max(fz) > 0.5 * weight
+    finally:
+        env.close()
