@@ -1,0 +1,210 @@
+// C-ABI (include/legged_hip.h) for the environment step: context, HBM allocation, launches.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "lg_device.h"
+
+static thread_local std::string g_err;
+void lg_set_error(const std::string &s) { g_err = s; }
+
+extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
+extern "C" void lgk_torques(const DevParams *P, int n, hipStream_t s);
+extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s);
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
+extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
+
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            g_err = std::string(#x) + ": " + hipGetErrorString(e_);                                \
+            return -100;                                                                           \
+        }                                                                                          \
+    } while (0)
+
+template <typename T>
+static int dalloc(lg_ctx *c, T **p, size_t n, bool zero = true) {
+    void *q = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    if (hipMalloc(&q, bytes) != hipSuccess) { g_err = "hipMalloc failed"; return -100; }
+    if (zero && hipMemset(q, 0, bytes) != hipSuccess) { g_err = "hipMemset failed"; return -100; }
+    if (c->n_allocs >= 64) { g_err = "alloc table full"; return -101; }
+    c->allocs[c->n_allocs++] = q;
+    *p = (T *)q;
+    return 0;
+}
+#define DA(ptr, n) do { int rc_ = dalloc(c, &(ptr), (n)); if (rc_) { lg_destroy(c); return rc_; } } while (0)
+
+extern "C" {
+
+const char *lg_last_error(void) { return g_err.c_str(); }
+int lg_version(void) { return 1; }
+
+int lg_destroy(lg_ctx *c) {
+    if (!c) return 0;
+    for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
+    delete c;
+    return 0;
+}
+
+int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_samples, lg_ctx **out) {
+    if (!cfg || !model || !out) { g_err = "null argument"; return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_err = "no HIP device: liblegged_hip has no CPU fallback";
+        return -2;
+    }
+    const int N = cfg->num_envs, A = cfg->num_actions, B = cfg->num_bodies, O = cfg->num_obs;
+    const int F = cfg->num_feet, H = cfg->num_height_points;
+    const int L = model->num_legs, J = model->joints_per_leg;
+    if (N <= 0 || A != L * J || A > LG_MAX_DOF || B > LG_MAX_BODIES || F > LG_MAX_FEET || L > 8) {
+        g_err = "unsupported sizes (num_envs/num_actions/bodies/feet/legs)";
+        return -3;
+    }
+    if (!((L == 4 && J == 3) || (L == 2 && J == 6))) {
+        g_err = "no physics kernel instantiated for this topology (have 4x3 and 2x6)";
+        return -4;
+    }
+    if (O != 12 + 3 * A + (cfg->measure_heights ? H : 0)) { g_err = "num_obs inconsistent with the observation layout"; return -5; }
+    if (cfg->terrain_type == 1 && !height_samples) { g_err = "terrain_type=1 needs height samples"; return -6; }
+    if (!cfg->noise_vec) { g_err = "cfg.noise_vec is null"; return -7; }
+
+    lg_ctx *c = new lg_ctx();
+    memset(c, 0, sizeof(*c));
+    c->init_done = 1;
+    DevParams &h = c->h;
+    h.cfg = *cfg;
+    h.model = *model;
+    h.cfg.noise_vec = h.cfg.height_points = h.cfg.terrain_origins = nullptr;
+    h.K = LG_SLOT_NOISE(A) + O;
+
+    // sphere slots per leg (same link pattern on every leg) + base spheres one per lane
+    {
+        int cnt[8] = {0};
+        h.n_leg_slots = 0;
+        h.n_base_spheres = 0;
+        for (int k = 0; k < model->num_spheres; ++k) {
+            int l = model->sph_link[k];
+            if (l < 0) {
+                int b = h.n_base_spheres++;
+                if (b >= L) { g_err = "more base collision spheres than legs"; delete c; return -8; }
+                h.base_body[b] = model->sph_body[k];
+                memcpy(h.base_center[b], model->sph_center[k], 12);
+                h.base_radius[b] = model->sph_radius[k];
+            } else {
+                int leg = l / J, s = cnt[leg]++;
+                if (s >= LG_MAX_LEG_SLOTS) { g_err = "too many collision spheres on one leg"; delete c; return -9; }
+                if (leg == 0) h.slot_link[s] = l % J;
+                else if (h.slot_link[s] != l % J) { g_err = "legs differ in their sphere->link pattern"; delete c; return -10; }
+                h.slot_body[s][leg] = model->sph_body[k];
+                memcpy(h.slot_center[s][leg], model->sph_center[k], 12);
+                h.slot_radius[s][leg] = model->sph_radius[k];
+            }
+        }
+        h.n_leg_slots = cnt[0];
+        for (int l = 1; l < L; ++l)
+            if (cnt[l] != cnt[0]) { g_err = "legs differ in their number of collision spheres"; delete c; return -11; }
+    }
+
+    lg_buffers &b = h.buf;
+    DA(b.root_states, (size_t)N * 13); DA(b.dof_state, (size_t)N * A * 2); DA(b.contact_forces, (size_t)N * B * 3);
+    DA(b.torques, (size_t)N * A); DA(b.actions, (size_t)N * A); DA(b.obs, (size_t)N * O); DA(b.rew, N);
+    DA(b.reset, N); DA(b.time_out, N); DA(b.episode_length, N);
+    DA(b.commands, (size_t)N * 4); DA(b.last_actions, (size_t)N * A); DA(b.last_dof_vel, (size_t)N * A);
+    DA(b.last_root_vel, (size_t)N * 6); DA(b.feet_air_time, (size_t)N * F); DA(b.last_contacts, (size_t)N * F);
+    DA(b.episode_sums, (size_t)LG_NUM_REWARDS * N); DA(b.base_lin_vel, (size_t)N * 3); DA(b.base_ang_vel, (size_t)N * 3);
+    DA(b.projected_gravity, (size_t)N * 3); DA(b.measured_heights, (size_t)N * (H ? H : 1));
+    DA(b.env_origins, (size_t)N * 3); DA(b.terrain_levels, N); DA(b.terrain_types, N);
+    DA(b.lstm_h, (size_t)2 * N * A * 8); DA(b.lstm_c, (size_t)2 * N * A * 8);
+    DA(b.friction, N); DA(b.base_mass_delta, N);
+    DA(b.extras_episode, LG_NUM_REWARDS); DA(b.extras_terrain_level, 1); DA(b.extras_time_outs, N); DA(b.n_reset, 1);
+    DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N);
+    DA(h.ep_accum, LG_NUM_REWARDS); DA(h.reset_count, 1);
+    {   // defaults: identity quaternion, unit friction, reset flags = 1 (base_task.py:72)
+        float *tmp = new float[(size_t)N * 13]();
+        for (int i = 0; i < N; ++i) tmp[(size_t)i * 13 + 6] = 1.0f;
+        (void)hipMemcpy(b.root_states, tmp, sizeof(float) * N * 13, hipMemcpyHostToDevice);
+        for (int i = 0; i < N; ++i) tmp[i] = 1.0f;
+        (void)hipMemcpy(b.friction, tmp, sizeof(float) * N, hipMemcpyHostToDevice);
+        delete[] tmp;
+        (void)hipMemset(b.reset, 1, N);
+    }
+    float *nv = nullptr, *hp = nullptr, *to = nullptr;
+    int16_t *hs = nullptr;
+    DA(nv, O);
+    HIPCHK(hipMemcpy(nv, cfg->noise_vec, sizeof(float) * O, hipMemcpyHostToDevice));
+    h.noise_vec = nv;
+    if (H) {
+        if (!cfg->height_points) { g_err = "cfg.height_points is null"; lg_destroy(c); return -12; }
+        DA(hp, (size_t)H * 2);
+        HIPCHK(hipMemcpy(hp, cfg->height_points, sizeof(float) * H * 2, hipMemcpyHostToDevice));
+    }
+    h.height_points = hp;
+    if (cfg->terrain_origins && cfg->max_terrain_level > 0) {
+        size_t n = (size_t)cfg->max_terrain_level * cfg->terrain_num_cols * 3;
+        DA(to, n);
+        HIPCHK(hipMemcpy(to, cfg->terrain_origins, sizeof(float) * n, hipMemcpyHostToDevice));
+    }
+    h.terrain_origins = to;
+    if (cfg->terrain_type == 1) {
+        size_t n = (size_t)cfg->hf_rows * cfg->hf_cols;
+        DA(hs, n);
+        HIPCHK(hipMemcpy(hs, height_samples, sizeof(int16_t) * n, hipMemcpyHostToDevice));
+    }
+    h.height_samples = hs;
+    DA(c->d, 1);
+    HIPCHK(hipMemcpy(c->d, &h, sizeof(DevParams), hipMemcpyHostToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+int lg_get_buffers(lg_ctx *c, lg_buffers *out) { if (!c || !out) return -1; *out = c->h.buf; return 0; }
+int lg_set_stream(lg_ctx *c, void *stream) { c->stream = (hipStream_t)stream; return 0; }
+int lg_set_step_counter(lg_ctx *c, int64_t v) { c->step_counter = v; return 0; }
+int64_t lg_get_step_counter(lg_ctx *c) { return c->step_counter; }
+int lg_set_init_done(lg_ctx *c, int v) { c->init_done = v; return 0; }
+int lg_inject_uniforms(lg_ctx *c, int enable) { c->inject = enable; return 0; }
+
+static int chk_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_err = std::string("kernel launch: ") + hipGetErrorString(e); return -100; }
+    return 0;
+}
+
+int lg_set_actions(lg_ctx *c, const float *actions) {
+    lgk_set_actions(c->d, actions, c->h.cfg.num_envs * c->h.cfg.num_actions, c->stream);
+    return chk_launch();
+}
+int lg_compute_torques(lg_ctx *c) {
+    lgk_torques(c->d, c->h.cfg.num_envs * c->h.cfg.num_actions, c->stream);
+    return chk_launch();
+}
+int lg_simulate(lg_ctx *c) {
+    if (lgk_physics(c->d, c->h.cfg.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg, c->stream)) {
+        g_err = "no physics kernel for this topology";
+        return -4;
+    }
+    return chk_launch();
+}
+int lg_post_physics_step(lg_ctx *c) {
+    c->step_counter += 1;                                       // legged_robot.py:115
+    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
+    return chk_launch();
+}
+int lg_reset_all(lg_ctx *c) {
+    lgk_reset_all(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
+    return chk_launch();
+}
+int lg_step(lg_ctx *c, const float *actions) {                  // legged_robot.py:80-104
+    int rc = lg_set_actions(c, actions);
+    for (int d = 0; d < c->h.cfg.decimation && !rc; ++d) {
+        rc = lg_compute_torques(c);
+        if (!rc) rc = lg_simulate(c);
+    }
+    if (!rc) rc = lg_post_physics_step(c);
+    return rc;
+}
+
+}  // extern "C"

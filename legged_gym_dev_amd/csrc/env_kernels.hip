@@ -1,0 +1,531 @@
+// Environment step kernels for gfx950 (wave64).  Reference semantics: LeggedRobot.step /
+// post_physics_step (legged_gym/envs/base/legged_robot.py:80-226, "LR"), Anymal._compute_torques
+// (envs/anymal_c/anymal.py:71-81, "AN"), Cassie._reward_no_fly (envs/cassie/cassie.py:43-46, "CA").
+#include "lg_device.h"
+#include "lg_physics.h"
+
+// ------------------------------------------------------------------------------------------------
+// LR:86-87  actions = clip(actions, +-clip_actions)
+__global__ void k_set_actions(const DevParams *__restrict__ P, const float *__restrict__ a_in) {
+    const int n = P->cfg.num_envs * P->cfg.num_actions;
+    const float c = P->cfg.clip_actions;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        P->buf.actions[i] = fminf(fmaxf(a_in[i], -c), c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Torque laws, one lane per (env, joint).  The actuator net (AN:71-81 + archive forward, SURVEY
+// Appendix C) keeps its 32 state floats in VGPRs; the 972 weights are wave-uniform scalar loads.
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float lstm_row(const float *__restrict__ w, float x0, float x1, float *h0, float *c0, float *h1,
+                                          float *c1) {
+    const float *wih0 = w + 3, *whh0 = wih0 + 64, *bih0 = whh0 + 256, *bhh0 = bih0 + 32;
+    const float *wih1 = bhh0 + 32, *whh1 = wih1 + 256, *bih1 = whh1 + 256, *bhh1 = bih1 + 32;
+    const float *lw = bhh1 + 32, *lb = lw + 8;
+    const float in0 = x0 * w[0], in1 = x1 * w[1];
+    float g[32], hin[8];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        float s = bih0[r] + bhh0[r];
+        s += wih0[r * 2] * in0;
+        s += wih0[r * 2 + 1] * in1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += whh0[r * 8 + k] * h0[k];
+        g[r] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float cn = sigm(g[8 + k]) * c0[k] + sigm(g[k]) * tanhf(g[16 + k]);
+        c0[k] = cn;
+        hin[k] = sigm(g[24 + k]) * tanhf(cn);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h0[k] = hin[k];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        float s = bih1[r] + bhh1[r];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += wih1[r * 8 + k] * hin[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += whh1[r * 8 + k] * h1[k];
+        g[r] = s;
+    }
+    float y = lb[0];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float cn = sigm(g[8 + k]) * c1[k] + sigm(g[k]) * tanhf(g[16 + k]);
+        c1[k] = cn;
+        float hn = sigm(g[24 + k]) * tanhf(cn);
+        h1[k] = hn;
+        y += lw[k] * hn;
+    }
+    return w[2] * y;
+}
+
+__global__ void __launch_bounds__(256) k_torques(const DevParams *__restrict__ P) {
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions, n = c.num_envs * A;
+    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ij >= n) return;
+    const int j = ij % A;
+    const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[ij];
+    const float q = st.x, qd = st.y;
+    const float as = P->buf.actions[ij] * c.action_scale;
+    float tau;
+    if (c.use_actuator_net) {
+        const size_t ls = (size_t)n * 8;
+        float h0[8], c0[8], h1[8], c1[8];
+        float4 *hp = reinterpret_cast<float4 *>(P->buf.lstm_h + (size_t)ij * 8);
+        float4 *cp = reinterpret_cast<float4 *>(P->buf.lstm_c + (size_t)ij * 8);
+        float4 *hp1 = reinterpret_cast<float4 *>(P->buf.lstm_h + ls + (size_t)ij * 8);
+        float4 *cp1 = reinterpret_cast<float4 *>(P->buf.lstm_c + ls + (size_t)ij * 8);
+        *reinterpret_cast<float4 *>(h0) = hp[0]; *reinterpret_cast<float4 *>(h0 + 4) = hp[1];
+        *reinterpret_cast<float4 *>(c0) = cp[0]; *reinterpret_cast<float4 *>(c0 + 4) = cp[1];
+        *reinterpret_cast<float4 *>(h1) = hp1[0]; *reinterpret_cast<float4 *>(h1 + 4) = hp1[1];
+        *reinterpret_cast<float4 *>(c1) = cp1[0]; *reinterpret_cast<float4 *>(c1 + 4) = cp1[1];
+        tau = lstm_row(c.lstm_w, as + c.default_dof_pos[j] - q, qd, h0, c0, h1, c1);
+        hp[0] = *reinterpret_cast<float4 *>(h0); hp[1] = *reinterpret_cast<float4 *>(h0 + 4);
+        cp[0] = *reinterpret_cast<float4 *>(c0); cp[1] = *reinterpret_cast<float4 *>(c0 + 4);
+        hp1[0] = *reinterpret_cast<float4 *>(h1); hp1[1] = *reinterpret_cast<float4 *>(h1 + 4);
+        cp1[0] = *reinterpret_cast<float4 *>(c1); cp1[1] = *reinterpret_cast<float4 *>(c1 + 4);
+    } else {                                                    // LR:389-413
+        if (c.control_type == 0) tau = c.p_gains[j] * (as + c.default_dof_pos[j] - q) - c.d_gains[j] * qd;
+        else if (c.control_type == 1)
+            tau = c.p_gains[j] * (as - qd) - c.d_gains[j] * (qd - P->buf.last_dof_vel[ij]) / c.sim_dt;
+        else tau = as;
+        tau = clampf(tau, -c.torque_limits[j], c.torque_limits[j]);
+    }
+    P->buf.torques[ij] = tau;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gym.simulate replacement (LR:92-96): one wave = 64/L environments, lane = (env, leg).
+template <int L, int J>
+__global__ void __launch_bounds__(64) k_physics(const DevParams *__restrict__ P) {
+    const lg_cfg &c = P->cfg;
+    const lg_model &m = P->model;
+    const int gl = blockIdx.x * 64 + threadIdx.x;
+    int env = gl / L;
+    const int leg = gl % L;
+    const bool live = env < c.num_envs;
+    if (!live) env = c.num_envs - 1;                        // keep the wave converged for the butterflies
+    const int A = L * J, B = c.num_bodies, d0 = leg * J;
+    float root[13], q[J], qd[J], tau[J];
+    const float *rp = P->buf.root_states + (size_t)env * 13;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) root[k] = rp[k];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[(size_t)env * A + d0 + j];
+        q[j] = st.x; qd[j] = st.y;
+        tau[j] = P->buf.torques[(size_t)env * A + d0 + j];
+    }
+    const float fr = P->buf.friction[env], dm = P->buf.base_mass_delta[env];
+    float *cf = P->buf.contact_forces + (size_t)env * B * 3;
+    if (live)
+        for (int b = 0; b < B; ++b) {
+            const int dyn = m.body_dyn[b];
+            if ((dyn < 0 ? 0 : dyn / J) == leg) { cf[3 * b] = 0.f; cf[3 * b + 1] = 0.f; cf[3 * b + 2] = 0.f; }
+        }
+    const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
+    const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
+    for (int s = 0; s < ns; ++s) {
+        V3 fslot[LG_MAX_LEG_SLOTS], fbase;
+        physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase);
+        V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k)
+                if (k < P->n_leg_slots) {
+                    float *o = cf + 3 * P->slot_body[k][leg];
+                    o[0] += wgt * fslot[k].x; o[1] += wgt * fslot[k].y; o[2] += wgt * fslot[k].z;
+                }
+            if (leg == 0 && P->n_base_spheres > 0) {
+                float *o = cf + 3 * P->base_body[0];
+                o[0] += wgt * fb.x; o[1] += wgt * fb.y; o[2] += wgt * fb.z;
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)env * A + d0 + j] = make_float2(q[j], qd[j]);
+    if (leg == 0) {
+        float *wp = P->buf.root_states + (size_t)env * 13;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) wp[k] = root[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// post_physics_step (LR:106-137) + observation clip (LR:100-103), one workgroup per tile of envs.
+__device__ __forceinline__ float uni(const DevParams *P, int env, int slot, int64_t counter, int inject) {
+    if (inject) return P->buf.inject_uniforms[(size_t)env * P->K + slot];
+    return philox_uniform(P->cfg.seed, (uint32_t)(P->cfg.env_offset + env), (uint64_t)counter, (uint32_t)slot);
+}
+
+__device__ void resample_commands(const DevParams *P, int i, int slot0, int64_t counter, int inject) {   // LR:365-387
+    const lg_cfg &c = P->cfg;
+    float *cmd = P->buf.commands + (size_t)i * 4;
+    float c0 = (c.cmd_hi[0] - c.cmd_lo[0]) * uni(P, i, slot0 + 0, counter, inject) + c.cmd_lo[0];
+    float c1 = (c.cmd_hi[1] - c.cmd_lo[1]) * uni(P, i, slot0 + 1, counter, inject) + c.cmd_lo[1];
+    float u2 = uni(P, i, slot0 + 2, counter, inject);
+    if (c.heading_command) cmd[3] = (c.cmd_hi[3] - c.cmd_lo[3]) * u2 + c.cmd_lo[3];
+    else cmd[2] = (c.cmd_hi[2] - c.cmd_lo[2]) * u2 + c.cmd_lo[2];
+    float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.0f : 0.0f;
+    cmd[0] = c0 * keep;
+    cmd[1] = c1 * keep;
+}
+
+__device__ __forceinline__ float fnorm3(const float *f) { return sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]); }
+
+struct RewardCtx {
+    V3 blv, bav, pg;
+    const float *cmd, *cf, *tau, *act, *lact, *lqd;
+    const float *dof;   // interleaved q, qd
+    float root_z;
+    bool reset, time_out;
+};
+
+__device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &x) {   // LR:918-1015, CA:43-46
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions, F = c.num_feet, H = c.num_height_points;
+    float s = 0.0f;
+    switch (k) {
+    case LG_REW_LIN_VEL_Z: return x.blv.z * x.blv.z;
+    case LG_REW_ANG_VEL_XY: return x.bav.x * x.bav.x + x.bav.y * x.bav.y;
+    case LG_REW_ORIENTATION: return x.pg.x * x.pg.x + x.pg.y * x.pg.y;
+    case LG_REW_BASE_HEIGHT: {
+        const float *hh = P->buf.measured_heights + (size_t)i * H;
+        for (int h = 0; h < H; ++h) s += x.root_z - hh[h];
+        float bh = s / (float)H;
+        return (bh - c.base_height_target) * (bh - c.base_height_target);
+    }
+    case LG_REW_TORQUES: for (int j = 0; j < A; ++j) s += x.tau[j] * x.tau[j]; return s;
+    case LG_REW_DOF_VEL: for (int j = 0; j < A; ++j) s += x.dof[2 * j + 1] * x.dof[2 * j + 1]; return s;
+    case LG_REW_DOF_ACC:
+        for (int j = 0; j < A; ++j) { float a = (x.lqd[j] - x.dof[2 * j + 1]) / c.dt; s += a * a; }
+        return s;
+    case LG_REW_ACTION_RATE:
+        for (int j = 0; j < A; ++j) { float a = x.lact[j] - x.act[j]; s += a * a; }
+        return s;
+    case LG_REW_COLLISION:
+        for (int b = 0; b < c.num_pen; ++b) s += fnorm3(x.cf + 3 * c.pen_idx[b]) > 0.1f ? 1.0f : 0.0f;
+        return s;
+    case LG_REW_TERMINATION: return (x.reset && !x.time_out) ? 1.0f : 0.0f;
+    case LG_REW_DOF_POS_LIMITS:
+        for (int j = 0; j < A; ++j) {
+            float q = x.dof[2 * j];
+            s += -fminf(q - c.dof_pos_limits[j][0], 0.0f) + fmaxf(q - c.dof_pos_limits[j][1], 0.0f);
+        }
+        return s;
+    case LG_REW_DOF_VEL_LIMITS:
+        for (int j = 0; j < A; ++j)
+            s += clampf(fabsf(x.dof[2 * j + 1]) - c.dof_vel_limits[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
+        return s;
+    case LG_REW_TORQUE_LIMITS:
+        for (int j = 0; j < A; ++j) s += fmaxf(fabsf(x.tau[j]) - c.torque_limits[j] * c.soft_torque_limit, 0.0f);
+        return s;
+    case LG_REW_TRACKING_LIN_VEL: {
+        float dx = x.cmd[0] - x.blv.x, dy = x.cmd[1] - x.blv.y;
+        return expf(-(dx * dx + dy * dy) / c.tracking_sigma);
+    }
+    case LG_REW_TRACKING_ANG_VEL: {
+        float d = x.cmd[2] - x.bav.z;
+        return expf(-(d * d) / c.tracking_sigma);
+    }
+    case LG_REW_FEET_AIR_TIME: {
+        float *air = P->buf.feet_air_time + (size_t)i * F;
+        uint8_t *lc = P->buf.last_contacts + (size_t)i * F;
+        for (int f = 0; f < F; ++f) {
+            bool contact = x.cf[3 * c.feet_idx[f] + 2] > 1.0f;
+            bool filt = contact || lc[f];
+            lc[f] = contact;
+            float a = air[f];
+            float first = (a > 0.0f && filt) ? 1.0f : 0.0f;
+            a += c.dt;
+            s += (a - 0.5f) * first;
+            air[f] = filt ? 0.0f : a;
+        }
+        float cn = sqrtf(x.cmd[0] * x.cmd[0] + x.cmd[1] * x.cmd[1]);
+        return s * (cn > 0.1f ? 1.0f : 0.0f);
+    }
+    case LG_REW_STUMBLE: {
+        bool any = false;
+        for (int f = 0; f < F; ++f) {
+            const float *ff = x.cf + 3 * c.feet_idx[f];
+            any |= sqrtf(ff[0] * ff[0] + ff[1] * ff[1]) > 5.0f * fabsf(ff[2]);
+        }
+        return any ? 1.0f : 0.0f;
+    }
+    case LG_REW_STAND_STILL: {
+        for (int j = 0; j < A; ++j) s += fabsf(x.dof[2 * j] - c.default_dof_pos[j]);
+        float cn = sqrtf(x.cmd[0] * x.cmd[0] + x.cmd[1] * x.cmd[1]);
+        return s * (cn < 0.1f ? 1.0f : 0.0f);
+    }
+    case LG_REW_FEET_CONTACT_FORCES:
+        for (int f = 0; f < F; ++f) s += fmaxf(fnorm3(x.cf + 3 * c.feet_idx[f]) - c.max_contact_force, 0.0f);
+        return s;
+    case LG_REW_NO_FLY: {
+        int n = 0;
+        for (int f = 0; f < F; ++f) n += x.cf[3 * c.feet_idx[f] + 2] > 0.1f ? 1 : 0;
+        return n == 1 ? 1.0f : 0.0f;
+    }
+    }
+    return 0.0f;
+}
+
+// LR:147-187 (+:415-454, :463-486, AN:56-60) for one env
+__device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions, N = c.num_envs;
+    float *r = P->buf.root_states + (size_t)i * 13;
+    float *org = P->buf.env_origins + (size_t)i * 3;
+    float *cmd = P->buf.commands + (size_t)i * 4;
+    if (c.curriculum && init_done) {
+        float dx = r[0] - org[0], dy = r[1] - org[1];
+        float dist = sqrtf(dx * dx + dy * dy);
+        bool up = dist > c.terrain_env_length / 2.0f;
+        float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+        bool down = (dist < cn * c.episode_length_s * 0.5f) && !up;
+        int64_t lvl = P->buf.terrain_levels[i] + (up ? 1 : 0) - (down ? 1 : 0);
+        if (lvl >= c.max_terrain_level) {
+            if (inject) lvl = P->buf.inject_levels[i];
+            else {
+                lvl = (int64_t)(uni(P, i, LG_SLOT_LEVEL, counter, 0) * c.max_terrain_level);
+                if (lvl > c.max_terrain_level - 1) lvl = c.max_terrain_level - 1;
+            }
+        } else if (lvl < 0) lvl = 0;
+        P->buf.terrain_levels[i] = lvl;
+        const float *to = P->terrain_origins + ((size_t)lvl * c.terrain_num_cols + P->buf.terrain_types[i]) * 3;
+        org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
+    }
+    float2 *dof = reinterpret_cast<float2 *>(P->buf.dof_state) + (size_t)i * A;
+    for (int j = 0; j < A; ++j) {
+        float u = uni(P, i, LG_SLOT_DOF + j, counter, inject);
+        dof[j] = make_float2(c.default_dof_pos[j] * ((1.5f - 0.5f) * u + 0.5f), 0.0f);
+    }
+    for (int k = 0; k < 13; ++k) r[k] = c.base_init_state[k];
+    for (int k = 0; k < 3; ++k) r[k] += org[k];
+    if (c.custom_origins)
+        for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(P, i, LG_SLOT_XY(A) + k, counter, inject) + (-1.0f);
+    for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(P, i, LG_SLOT_VEL(A) + k, counter, inject) + (-0.5f);
+    resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
+    for (int j = 0; j < A; ++j) { P->buf.last_actions[(size_t)i * A + j] = 0.0f; P->buf.last_dof_vel[(size_t)i * A + j] = 0.0f; }
+    for (int f = 0; f < c.num_feet; ++f) P->buf.feet_air_time[(size_t)i * c.num_feet + f] = 0.0f;
+    P->buf.episode_length[i] = 0;
+    P->buf.reset[i] = 1;
+    if (c.use_actuator_net) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < 2; ++l)
+            for (int j = 0; j < A; ++j) {
+                size_t idx = ((size_t)l * N * A + (size_t)i * A + j) * 8;
+                float4 *hp = reinterpret_cast<float4 *>(P->buf.lstm_h + idx), *cp = reinterpret_cast<float4 *>(P->buf.lstm_c + idx);
+                hp[0] = z; hp[1] = z; cp[0] = z; cp[1] = z;
+            }
+    }
+}
+
+// LR:877-915 (+ utils/math.py:38-42): one lane per (env, height point)
+__device__ __forceinline__ float height_sample(const DevParams *P, const float *r, int h) {
+    const lg_cfg &c = P->cfg;
+    float qz = r[5], qw = r[6];
+    float n = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+    float qy[4] = {0.0f, 0.0f, qz / n, qw / n};
+    V3 w = quat_apply(qy, V3{P->height_points[2 * h], P->height_points[2 * h + 1], 0.0f});
+    float x = (w.x + r[0] + c.border_size) / c.hf_hscale;
+    float y = (w.y + r[1] + c.border_size) / c.hf_hscale;
+    int px = (int)x, py = (int)y;                                 // .long(): truncation toward zero
+    px = min(max(px, 0), c.hf_rows - 2);
+    py = min(max(py, 0), c.hf_cols - 2);
+    const int16_t *hs = P->height_samples + (size_t)px * c.hf_cols + py;
+    int16_t h1 = hs[0], h2 = hs[c.hf_cols], h3 = hs[1];
+    int16_t mn = h1 < h2 ? h1 : h2;
+    mn = mn < h3 ? mn : h3;
+    return (float)mn * c.hf_vscale;
+}
+
+template <int TILE>
+__global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *__restrict__ P, int64_t counter, int inject,
+                                                               int init_done) {
+    const lg_cfg &c = P->cfg;
+    const int N = c.num_envs, A = c.num_actions, B = c.num_bodies, O = c.num_obs, H = c.num_height_points;
+    const int env0 = blockIdx.x * TILE;
+    const int nE = min(TILE, N - env0);
+    const int tid = threadIdx.x;
+    __shared__ float s_acc[LG_NUM_REWARDS];
+    __shared__ int s_cnt;
+    if (tid < LG_NUM_REWARDS) s_acc[tid] = 0.0f;
+    if (tid == 0) s_cnt = 0;
+
+    // ---- phase H: height scan of the pre-reset pose (LR:356-357)
+    if (c.measure_heights) {
+        for (int idx = tid; idx < nE * H; idx += LG_TILE_THREADS) {
+            const int e = env0 + idx / H, h = idx % H;
+            float v = 0.0f;
+            if (c.terrain_type == 1) v = height_sample(P, P->buf.root_states + (size_t)e * 13, h);
+            P->buf.measured_heights[(size_t)e * H + h] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A: one lane per env: LR:111-129
+    if (tid < nE) {
+        const int i = env0 + tid;
+        float *r = P->buf.root_states + (size_t)i * 13;
+        float *cmd = P->buf.commands + (size_t)i * 4;
+        const float *cf = P->buf.contact_forces + (size_t)i * B * 3;
+        const int64_t ep = P->buf.episode_length[i] + 1;                   // LR:114
+        P->buf.episode_length[i] = ep;
+        RewardCtx x;
+        x.blv = quat_rotate_inverse(r + 3, V3{r[7], r[8], r[9]});        // LR:118-121
+        x.bav = quat_rotate_inverse(r + 3, V3{r[10], r[11], r[12]});
+        x.pg = quat_rotate_inverse(r + 3, V3{0.0f, 0.0f, -1.0f});
+        float *o3 = P->buf.base_lin_vel + 3 * (size_t)i;
+        o3[0] = x.blv.x; o3[1] = x.blv.y; o3[2] = x.blv.z;
+        o3 = P->buf.base_ang_vel + 3 * (size_t)i;
+        o3[0] = x.bav.x; o3[1] = x.bav.y; o3[2] = x.bav.z;
+        o3 = P->buf.projected_gravity + 3 * (size_t)i;
+        o3[0] = x.pg.x; o3[1] = x.pg.y; o3[2] = x.pg.z;
+        if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject);   // LR:348-350
+        if (c.heading_command) {                                            // LR:351-354, math.py:45-48
+            V3 fwd = quat_apply(r + 3, V3{1.0f, 0.0f, 0.0f});
+            float heading = atan2f(fwd.y, fwd.x);
+            const float two_pi = 6.283185307179586f;
+            float ang = fmodf(cmd[3] - heading, two_pi);
+            if (ang < 0.0f) ang += two_pi;
+            if (ang > 3.141592653589793f) ang -= two_pi;
+            cmd[2] = clampf(0.5f * ang, -1.0f, 1.0f);
+        }
+        if (c.push_robots && c.push_interval > 0 && (counter % c.push_interval == 0)) {   // LR:358-359,456-461
+            r[7] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH, counter, inject) + (-c.max_push_vel);
+            r[8] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH + 1, counter, inject) + (-c.max_push_vel);
+        }
+        bool rst = false;                                                   // LR:139-145
+        for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
+        const bool to = ep > c.max_episode_length;
+        rst = rst || to;
+        P->buf.time_out[i] = to;
+        P->buf.reset[i] = rst;
+        x.cmd = cmd; x.cf = cf; x.root_z = r[2]; x.reset = rst; x.time_out = to;
+        x.dof = P->buf.dof_state + (size_t)i * A * 2;
+        x.tau = P->buf.torques + (size_t)i * A; x.act = P->buf.actions + (size_t)i * A;
+        x.lact = P->buf.last_actions + (size_t)i * A; x.lqd = P->buf.last_dof_vel + (size_t)i * A;
+        float rew = 0.0f;                                                   // LR:189-206
+        for (int k = 0; k < LG_NUM_REWARDS; ++k) {
+            if (k == LG_REW_TERMINATION || c.rew_scale[k] == 0.0f) continue;
+            float v = reward_term(P, i, k, x) * c.rew_scale[k];
+            rew += v;
+            P->buf.episode_sums[(size_t)k * N + i] += v;
+        }
+        if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
+        if (c.rew_scale[LG_REW_TERMINATION] != 0.0f) {
+            float v = reward_term(P, i, LG_REW_TERMINATION, x) * c.rew_scale[LG_REW_TERMINATION];
+            rew += v;
+            P->buf.episode_sums[(size_t)LG_REW_TERMINATION * N + i] += v;
+        }
+        P->buf.rew[i] = rew;
+        if (rst) {                                                          // LR:147-187
+            atomicAdd(&s_cnt, 1);
+            for (int k = 0; k < LG_NUM_REWARDS; ++k)
+                if (c.rew_scale[k] != 0.0f) {
+                    atomicAdd(&s_acc[k], P->buf.episode_sums[(size_t)k * N + i]);
+                    P->buf.episode_sums[(size_t)k * N + i] = 0.0f;
+                }
+            reset_env(P, i, counter, inject, init_done);
+        }
+    }
+    __syncthreads();
+    if (s_cnt > 0) {
+        if (tid < LG_NUM_REWARDS && c.rew_scale[tid] != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
+        if (tid == 0) atomicAdd(P->reset_count, s_cnt);
+    }
+
+    // ---- phase O: observations (LR:208-226), clip (LR:100-103), bookkeeping (LR:132-134)
+    for (int idx = tid; idx < nE * O; idx += LG_TILE_THREADS) {
+        const int i = env0 + idx / O, k = idx % O;
+        const float *r = P->buf.root_states + (size_t)i * 13;
+        float v;
+        if (k < 3) v = P->buf.base_lin_vel[3 * (size_t)i + k] * c.obs_scale_lin_vel;
+        else if (k < 6) v = P->buf.base_ang_vel[3 * (size_t)i + k - 3] * c.obs_scale_ang_vel;
+        else if (k < 9) v = P->buf.projected_gravity[3 * (size_t)i + k - 6];
+        else if (k < 12) v = P->buf.commands[(size_t)i * 4 + k - 9] * (k == 11 ? c.obs_scale_ang_vel : c.obs_scale_lin_vel);
+        else if (k < 12 + A) v = (P->buf.dof_state[((size_t)i * A + k - 12) * 2] - c.default_dof_pos[k - 12]) * c.obs_scale_dof_pos;
+        else if (k < 12 + 2 * A) v = P->buf.dof_state[((size_t)i * A + k - 12 - A) * 2 + 1] * c.obs_scale_dof_vel;
+        else if (k < 12 + 3 * A) v = P->buf.actions[(size_t)i * A + k - 12 - 2 * A];
+        else v = clampf(r[2] - 0.5f - P->buf.measured_heights[(size_t)i * H + k - 12 - 3 * A], -1.0f, 1.0f) * c.obs_scale_height;
+        if (c.add_noise) v += (2.0f * uni(P, i, LG_SLOT_NOISE(A) + k, counter, inject) - 1.0f) * P->noise_vec[k];
+        P->buf.obs[(size_t)i * O + k] = clampf(v, -c.clip_obs, c.clip_obs);
+    }
+    for (int idx = tid; idx < nE * A; idx += LG_TILE_THREADS) {
+        const size_t ij = (size_t)env0 * A + idx;
+        P->buf.last_actions[ij] = P->buf.actions[ij];
+        P->buf.last_dof_vel[ij] = P->buf.dof_state[ij * 2 + 1];
+    }
+    for (int idx = tid; idx < nE * 6; idx += LG_TILE_THREADS) {
+        const int i = env0 + idx / 6, k = idx % 6;
+        P->buf.last_root_vel[(size_t)i * 6 + k] = P->buf.root_states[(size_t)i * 13 + 7 + k];
+    }
+}
+
+// Single-workgroup epilogue: extras["episode"], extras["time_outs"] (only refreshed when >=1 env
+// reset this step: the early return of LR:156-157 keeps the previous, stale values), terrain level mean.
+__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P) {
+    const lg_cfg &c = P->cfg;
+    const int N = c.num_envs, tid = threadIdx.x;
+    const int n = *P->reset_count;
+    __shared__ float s_red[256];
+    if (n > 0) {
+        if (tid < LG_NUM_REWARDS)
+            P->buf.extras_episode[tid] = c.rew_scale[tid] != 0.0f ? (P->ep_accum[tid] / (float)n) / c.episode_length_s : 0.0f;
+        if (c.send_timeouts)
+            for (int i = tid; i < N; i += 256) P->buf.extras_time_outs[i] = P->buf.time_out[i];
+        if (c.curriculum) {
+            float s = 0.0f;
+            for (int i = tid; i < N; i += 256) s += (float)P->buf.terrain_levels[i];
+            s_red[tid] = s;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if (tid < w) s_red[tid] += s_red[tid + w];
+                __syncthreads();
+            }
+            if (tid == 0) P->buf.extras_terrain_level[0] = s_red[0] / (float)N;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { P->buf.n_reset[0] = n; *P->reset_count = 0; }
+    if (tid < LG_NUM_REWARDS) P->ep_accum[tid] = 0.0f;
+}
+
+// reset_idx(arange(N)) (base_task.py:113): no logging
+__global__ void k_reset_all(const DevParams *__restrict__ P, int64_t counter, int inject, int init_done) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P->cfg.num_envs) return;
+    for (int k = 0; k < LG_NUM_REWARDS; ++k) P->buf.episode_sums[(size_t)k * P->cfg.num_envs + i] = 0.0f;
+    reset_env(P, i, counter, inject, init_done);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s) {
+    int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_set_actions, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, P, a);
+}
+extern "C" void lgk_torques(const DevParams *P, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_torques, dim3((n + 255) / 256), dim3(256), 0, s, P);
+}
+extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s) {
+    const int blocks = (N * L + 63) / 64;
+    if (L == 4 && J == 3) hipLaunchKernelGGL((k_physics<4, 3>), dim3(blocks), dim3(64), 0, s, P);
+    else if (L == 2 && J == 6) hipLaunchKernelGGL((k_physics<2, 6>), dim3(blocks), dim3(64), 0, s, P);
+    else return -1;
+    return 0;
+}
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
+    constexpr int TILE = 16;
+    hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P);
+}
+extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);
+}

@@ -1,0 +1,119 @@
+// Device-side common definitions for liblegged_hip.so (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/legged_hip.h"
+
+#define LG_WAVE 64
+#define LG_TILE_THREADS 256
+#define LG_MAX_LEG_SLOTS 6
+
+// Everything a kernel needs, resident in HBM and passed by pointer: uniform (scalar-unit) loads.
+struct DevParams {
+    lg_cfg cfg;          // host pointers inside are NOT valid on device (use the ones below)
+    lg_model model;
+    lg_buffers buf;
+    const float *noise_vec;        // num_obs
+    const float *height_points;    // H x 2
+    const float *terrain_origins;  // levels x types x 3
+    const int16_t *height_samples; // hf_rows x hf_cols
+    float *ep_accum;               // LG_NUM_REWARDS sums of episode_sums over resetting envs
+    int32_t *reset_count;          // 1
+    int K;                         // uniforms per env
+    // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
+    int n_leg_slots, n_base_spheres;
+    int slot_link[LG_MAX_SPHERES];           // joint index within the chain (same for every leg)
+    int slot_body[LG_MAX_SPHERES][4 + 4];    // [slot][leg] body row (legs <= 8)
+    float slot_center[LG_MAX_SPHERES][8][3];
+    float slot_radius[LG_MAX_SPHERES][8];
+    int base_body[8];
+    float base_center[8][3];
+    float base_radius[8];
+};
+
+struct lg_ctx {
+    DevParams h;              // host copy
+    DevParams *d;             // device copy
+    hipStream_t stream;
+    int64_t step_counter;
+    int init_done, inject;
+    void *allocs[64];
+    int n_allocs;
+};
+
+// ------------------------------------------------------------------ small vector algebra
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+struct M3 { float m[3][3]; };
+__device__ __forceinline__ V3 mul(const M3 &A, V3 v) {
+    return {A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z, A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
+            A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z};
+}
+__device__ __forceinline__ V3 mulT(const M3 &A, V3 v) {
+    return {A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z, A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z,
+            A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z};
+}
+__device__ __forceinline__ M3 mul(const M3 &A, const M3 &B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+    return C;
+}
+__device__ __forceinline__ M3 mulBT(const M3 &A, const M3 &B) {   // A * B^T
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[j][0] + A.m[i][1] * B.m[j][1] + A.m[i][2] * B.m[j][2];
+    return C;
+}
+__device__ __forceinline__ M3 load3(const float *p) {
+    M3 A;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A.m[i / 3][i % 3] = p[i];
+    return A;
+}
+__device__ __forceinline__ V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+
+// isaacgym.torch_utils.quat_rotate_inverse / quat_apply, q = xyzw
+__device__ __forceinline__ V3 quat_rotate_inverse(const float *q, V3 v) {
+    V3 qv = {q[0], q[1], q[2]};
+    float w = q[3], s = 2.0f * w * w - 1.0f;
+    V3 cr = cross(qv, v);
+    float d = dot(qv, v);
+    return {v.x * s - cr.x * w * 2.0f + qv.x * d * 2.0f, v.y * s - cr.y * w * 2.0f + qv.y * d * 2.0f,
+            v.z * s - cr.z * w * 2.0f + qv.z * d * 2.0f};
+}
+__device__ __forceinline__ V3 quat_apply(const float *q, V3 b) {
+    V3 qv = {q[0], q[1], q[2]};
+    V3 t = 2.0f * cross(qv, b);
+    return b + q[3] * t + cross(qv, t);
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t env, uint64_t step, uint32_t slot) {
+    uint32_t c[4] = {env, (uint32_t)step, slot >> 2, (uint32_t)(step >> 32)};
+    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
+    uint32_t r = (slot & 3) == 0 ? c[0] : (slot & 3) == 1 ? c[1] : (slot & 3) == 2 ? c[2] : c[3];
+    return (float)(r >> 8) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,452 @@
+// Lane-parallel articulated-body physics for gfx950: one lane per (environment, leg).
+//
+// Replaces gym.simulate() (reference call site legged_gym/envs/base/legged_robot.py:92-96).  The
+// algorithm is the build's own specification (oracle/lgo_physics.cpp restates it scalar, generic
+// tree): Featherstone ABA in base-frame coordinates about the base origin, exact 3x3 contact-space
+// inverse inertia per sphere contact from test impulses, projected-Jacobi contact sweeps, one tree
+// impulse propagation per sweep, semi-implicit Euler.
+//
+// Mapping to CDNA4: a wave64 holds 64/L environments; the L lanes of an environment own one leg
+// chain each (J revolute joints, fully unrolled so every per-joint quantity stays in VGPRs), and
+// meet only at the floating base through L-lane butterfly sums (ds_swizzle / DPP via __shfl_xor):
+// 27 floats for the articulated base inertia + bias, 6 floats per contact sweep.  No LDS, no
+// barriers, no divergence between legs; contact slots are skipped wave-uniformly (__any) when no
+// lane of the wave has that sphere near the ground.
+#pragma once
+#include "lg_device.h"
+
+struct Sv { V3 w, v; };
+__device__ __forceinline__ Sv operator+(Sv a, Sv b) { return {a.w + b.w, a.v + b.v}; }
+__device__ __forceinline__ Sv operator-(Sv a, Sv b) { return {a.w - b.w, a.v - b.v}; }
+__device__ __forceinline__ Sv operator*(float s, Sv a) { return {s * a.w, s * a.v}; }
+__device__ __forceinline__ float sdot(Sv a, Sv b) { return dot(a.w, b.w) + dot(a.v, b.v); }
+__device__ __forceinline__ Sv crm(Sv a, Sv b) { return {cross(a.w, b.w), cross(a.w, b.v) + cross(a.v, b.w)}; }
+__device__ __forceinline__ Sv crf(Sv a, Sv f) { return {cross(a.w, f.w) + cross(a.v, f.v), cross(a.w, f.v)}; }
+__device__ __forceinline__ Sv sv_zero() { return {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}; }
+
+struct M6 { float m[6][6]; };
+__device__ __forceinline__ Sv mul6(const M6 &I, Sv a) {
+    float x[6] = {a.w.x, a.w.y, a.w.z, a.v.x, a.v.y, a.v.z}, y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s += I.m[i][j] * x[j];
+        y[i] = s;
+    }
+    return {{y[0], y[1], y[2]}, {y[3], y[4], y[5]}};
+}
+__device__ __forceinline__ M6 rigid_inertia(float m, V3 c, const M3 &Ic) {
+    M6 I;
+    float cc = dot(c, c);
+    float cv[3] = {c.x, c.y, c.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            I.m[i][j] = Ic.m[i][j] + m * ((i == j ? cc : 0.0f) - cv[i] * cv[j]);
+            I.m[3 + i][3 + j] = (i == j) ? m : 0.0f;
+        }
+    float hx[3][3] = {{0.f, -m * c.z, m * c.y}, {m * c.z, 0.f, -m * c.x}, {-m * c.y, m * c.x, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { I.m[i][3 + j] = hx[i][j]; I.m[3 + i][j] = hx[j][i]; }
+    return I;
+}
+__device__ __forceinline__ bool spd_inverse6(const M6 &A, M6 &Ainv) {
+    float Lm[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Lm[i][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = A.m[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
+            if (i == j) { ok = ok && (s > 0.0f); Lm[i][i] = sqrtf(fmaxf(s, 1e-30f)); }
+            else Lm[i][j] = s / Lm[j][j];
+        }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float y[6], x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float s = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= Lm[i][k] * y[k];
+            y[i] = s / Lm[i][i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            float s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) s -= Lm[k][i] * x[k];
+            x[i] = s / Lm[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ainv.m[i][c] = x[i];
+    }
+    return ok;
+}
+__device__ __forceinline__ M3 rodrigues(V3 a, float th) {
+    float s, c;
+    sincosf(th, &s, &c);
+    float t = 1.0f - c;
+    M3 R = {{{c + t * a.x * a.x, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y},
+             {t * a.x * a.y + s * a.z, c + t * a.y * a.y, t * a.y * a.z - s * a.x},
+             {t * a.x * a.z - s * a.y, t * a.y * a.z + s * a.x, c + t * a.z * a.z}}};
+    return R;
+}
+__device__ __forceinline__ M3 quat_to_mat(const float *q) {
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    M3 R = {{{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+             {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+             {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}}};
+    return R;
+}
+
+template <int L>
+__device__ __forceinline__ float leg_sum(float x) {     // sum over the L lanes of one environment
+#pragma unroll
+    for (int m = 1; m < L; m <<= 1) x += __shfl_xor(x, m);
+    return x;
+}
+template <int L>
+__device__ __forceinline__ Sv leg_sum(Sv a) {
+    return {{leg_sum<L>(a.w.x), leg_sum<L>(a.w.y), leg_sum<L>(a.w.z)}, {leg_sum<L>(a.v.x), leg_sum<L>(a.v.y), leg_sum<L>(a.v.z)}};
+}
+
+struct Ground { float h; V3 n; };
+__device__ __forceinline__ Ground ground_at(const DevParams *P, float x, float y) {
+    const lg_cfg &c = P->cfg;
+    if (c.terrain_type == 0) return {0.0f, {0.0f, 0.0f, 1.0f}};
+    float gx = (x + c.border_size) / c.hf_hscale, gy = (y + c.border_size) / c.hf_hscale;
+    gx = fminf(fmaxf(gx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
+    gy = fminf(fmaxf(gy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
+    int ix = (int)gx, iy = (int)gy;
+    float tx = gx - ix, ty = gy - iy;
+    const int16_t *hs = P->height_samples + (size_t)ix * c.hf_cols + iy;
+    float h00 = (float)hs[0] * c.hf_vscale, h01 = (float)hs[1] * c.hf_vscale;
+    float h10 = (float)hs[c.hf_cols] * c.hf_vscale, h11 = (float)hs[c.hf_cols + 1] * c.hf_vscale;
+    float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
+    float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hf_hscale;
+    float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hf_hscale;
+    float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    return {h, {-dhdx * inv, -dhdy * inv, inv}};
+}
+
+
+
+struct Contact {           // one sphere slot of this lane
+    V3 P, n;
+    float W00, W10, W20, W11, W21, W22;
+    float vtarget, relax, ln, l1, l2;
+    bool active;
+};
+__device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
+    V3 ref = fabsf(n.x) < 0.9f ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f};
+    V3 t = cross(n, ref);
+    t1 = (1.0f / sqrtf(dot(t, t))) * t;
+    t2 = cross(n, t1);
+}
+
+// One physics step of length dt for lane (env, leg).  State in/out through registers:
+//   root[13] (world: pos, quat xyzw, lin vel, ang vel), q[J], qd[J] of this leg's joints.
+// fslot[s] / fbase receive the world-frame contact force (N) of this lane's sphere slots.
+template <int L, int J>
+__device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
+                                             float *qd, const float *tau, float friction, float dmass,
+                                             V3 *fslot, V3 &fbase) {
+    const lg_cfg &c = P->cfg;
+    const lg_model &m = P->model;
+    const int d0 = leg * J;
+    const M3 Rb = quat_to_mat(root + 3);
+    const V3 xw = {root[0], root[1], root[2]};
+    const V3 vb = mulT(Rb, V3{root[7], root[8], root[9]}), wb = mulT(Rb, V3{root[10], root[11], root[12]});
+    const V3 gb = mulT(Rb, V3{c.gravity[0], c.gravity[1], c.gravity[2]});
+    const Sv vel0 = {wb, vb};
+
+    M3 Rl[J];
+    V3 pl[J];
+    Sv S[J], vel[J], cb[J], U[J];
+    float D[J], u[J];
+    {   // outward kinematics
+        M3 Rpar = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
+        V3 ppar = {0.f, 0.f, 0.f};
+        Sv vpar = vel0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int d = d0 + j;
+            M3 Rj = mul(Rpar, load3(m.R_pj[d]));
+            V3 ax = ld3(m.axis[d]);
+            pl[j] = ppar + mul(Rpar, ld3(m.p_pj[d]));
+            V3 axb = mul(Rj, ax);
+            Rl[j] = mul(Rj, rodrigues(ax, q[j]));
+            S[j] = {axb, cross(pl[j], axb)};
+            Sv vj = qd[j] * S[j];
+            vel[j] = vpar + vj;
+            cb[j] = crm(vel[j], vj);
+            Rpar = Rl[j]; ppar = pl[j]; vpar = vel[j];
+        }
+    }
+    // inward pass along the chain
+    M6 Ia_run;
+    Sv pa_run = sv_zero();
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) Ia_run.m[a][b] = 0.f;
+#pragma unroll
+    for (int j = J - 1; j >= 0; --j) {
+        const int d = d0 + j;
+        M3 Ic = mulBT(mul(Rl[j], load3(m.inertia[d + 1])), Rl[j]);
+        M6 IA = rigid_inertia(m.mass[d + 1], pl[j] + mul(Rl[j], ld3(m.com[d + 1])), Ic);
+        Sv pA = crf(vel[j], mul6(IA, vel[j]));
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) IA.m[a][b] += Ia_run.m[a][b];
+        pA = pA + pa_run;
+        U[j] = mul6(IA, S[j]);
+        D[j] = sdot(S[j], U[j]);
+        u[j] = (tau[j] - m.joint_damping[d] * qd[j]) - sdot(S[j], pA);
+        float Uv[6] = {U[j].w.x, U[j].w.y, U[j].w.z, U[j].v.x, U[j].v.y, U[j].v.z};
+        float invD = 1.0f / D[j];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) Ia_run.m[a][b] = IA.m[a][b] - Uv[a] * Uv[b] * invD;
+        pa_run = pA + mul6(Ia_run, cb[j]) + (u[j] * invD) * U[j];
+    }
+    // floating base: own inertia (every lane redundantly) + butterfly sum of the L leg contributions
+    M6 I0;
+    {
+        float mb = m.mass[0] + dmass;
+        I0 = rigid_inertia(mb, ld3(m.com[0]), load3(m.inertia[0]));
+    }
+    Sv pA0 = crf(vel0, mul6(I0, vel0)) + leg_sum<L>(pa_run);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            float s = leg_sum<L>(Ia_run.m[a][b]);
+            I0.m[a][b] += s;
+            if (b != a) I0.m[b][a] += s;
+        }
+    M6 I0inv;
+    const bool ok = spd_inverse6(I0, I0inv);
+    const Sv a0 = -1.0f * mul6(I0inv, pA0);
+    // outward accelerations -> free velocities
+    Sv velf[J], velf0;
+    float qdf[J];
+    {
+        const Sv grav = {{0.f, 0.f, 0.f}, gb};
+        velf0 = vel0 + dt * (a0 + grav);
+        Sv apar = a0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            Sv ap = apar + cb[j];
+            float qdd = (u[j] - sdot(U[j], ap)) / D[j];
+            Sv acc = ap + qdd * S[j];
+            velf[j] = vel[j] + dt * (acc + grav);
+            qdf[j] = qd[j] + dt * qdd;
+            apar = acc;
+        }
+    }
+
+    // ---- contact detection + W per slot
+    const float mu = 0.5f * (friction + c.ground_friction);
+    Contact ct[LG_MAX_LEG_SLOTS + 1];
+    int n_leg_active = 0;
+    const int nslots = P->n_leg_slots;
+#pragma unroll
+    for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) {
+        Contact &C = ct[s];
+        C.active = false;
+        C.ln = C.l1 = C.l2 = 0.f;
+        C.relax = 0.f;
+        const bool is_base = (s == LG_MAX_LEG_SLOTS);
+        bool exists = is_base ? (leg < P->n_base_spheres) : (s < nslots);
+        int jl = 0;
+        V3 cbk = {0.f, 0.f, 0.f};
+        float rad = 0.f;
+        if (exists) {
+            if (is_base) {
+                cbk = ld3(P->base_center[leg]);
+                rad = P->base_radius[leg];
+            } else {
+                jl = P->slot_link[s];
+                M3 Rk = Rl[0];
+                V3 pk = pl[0];
+#pragma unroll
+                for (int k = 1; k < J; ++k)
+                    if (jl == k) { Rk = Rl[k]; pk = pl[k]; }
+                cbk = pk + mul(Rk, ld3(P->slot_center[s][leg]));
+                rad = P->slot_radius[s][leg];
+            }
+            V3 cw = xw + mul(Rb, cbk);
+            Ground g = ground_at(P, cw.x, cw.y);
+            float gap = (cw.z - g.h) * g.n.z - rad;
+            if (gap < c.contact_offset) {
+                C.active = true;
+                C.n = mulT(Rb, g.n);
+                C.P = cbk - rad * C.n;
+                C.vtarget = gap >= 0.0f ? -gap / dt : fminf(-gap * c.contact_erp / dt, c.max_depenetration_velocity);
+            }
+        }
+        if (!__any(C.active)) continue;                  // wave-uniform skip
+        if (C.active && !is_base) n_leg_active++;
+        V3 t1, t2;
+        tangents(C.active ? C.n : V3{0.f, 0.f, 1.f}, t1, t2);
+        V3 dirs[3] = {C.active ? C.n : V3{0.f, 0.f, 1.f}, t1, t2};
+        float Wc[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            Sv pAi = {-1.0f * cross(C.P, dirs[a]), -1.0f * dirs[a]};
+            float ui[J];
+            if (!is_base) {
+#pragma unroll
+                for (int k = J - 1; k >= 0; --k) {
+                    if (k <= jl) {
+                        ui[k] = -sdot(S[k], pAi);
+                        pAi = pAi + (ui[k] / D[k]) * U[k];
+                    } else ui[k] = 0.f;
+                }
+            }
+            Sv dv = -1.0f * mul6(I0inv, pAi);
+            if (!is_base) {
+#pragma unroll
+                for (int k = 0; k < J; ++k)
+                    if (k <= jl) {
+                        float dq = (ui[k] - sdot(U[k], dv)) / D[k];
+                        dv = dv + dq * S[k];
+                    }
+            }
+            V3 dvP = dv.v + cross(dv.w, C.P);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
+        }
+        C.W00 = Wc[0][0]; C.W10 = Wc[1][0]; C.W20 = Wc[2][0]; C.W11 = Wc[1][1]; C.W21 = Wc[2][1]; C.W22 = Wc[2][2];
+    }
+    {
+        const int n_base_active = (int)leg_sum<L>(ct[LG_MAX_LEG_SLOTS].active ? 1.0f : 0.0f);
+#pragma unroll
+        for (int s = 0; s < LG_MAX_LEG_SLOTS; ++s) ct[s].relax = ct[s].active ? 1.0f / (float)n_leg_active : 0.f;
+        ct[LG_MAX_LEG_SLOTS].relax = ct[LG_MAX_LEG_SLOTS].active ? 1.0f / (float)n_base_active : 0.f;
+    }
+    bool any_contact = false;
+#pragma unroll
+    for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) any_contact |= ct[s].active;
+
+    // ---- projected Jacobi sweeps (wave-uniform trip count; contact-free waves skip them)
+    if (__any(any_contact)) {
+        for (int it = 0; it < c.solver_iterations; ++it) {
+            Sv fimp[J], fb = sv_zero();
+#pragma unroll
+            for (int k = 0; k < J; ++k) fimp[k] = sv_zero();
+#pragma unroll
+            for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) {
+                Contact &C = ct[s];
+                if (!__any(C.active)) continue;
+                const bool is_base = (s == LG_MAX_LEG_SLOTS);
+                const int jl = is_base ? 0 : P->slot_link[s < nslots ? s : 0];
+                Sv vl = velf0;
+                if (!is_base) {
+                    vl = velf[0];
+#pragma unroll
+                    for (int k = 1; k < J; ++k)
+                        if (jl == k) vl = velf[k];
+                }
+                if (C.active) {
+                    V3 t1, t2;
+                    tangents(C.n, t1, t2);
+                    V3 vP = vl.v + cross(vl.w, C.P);
+                    float vc0 = dot(C.n, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
+                    float ln = fmaxf(0.0f, C.ln - C.relax * (vc0 - C.vtarget) / C.W00);
+                    float dn = ln - C.ln;
+                    vc1 += C.W10 * dn;
+                    vc2 += C.W20 * dn;
+                    float l1 = C.l1 - C.relax * vc1 / C.W11;
+                    vc2 += C.W21 * (l1 - C.l1);
+                    float l2 = C.l2 - C.relax * vc2 / C.W22;
+                    float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
+                    if (mag > lim) { float sc = lim / fmaxf(mag, 1e-12f); l1 *= sc; l2 *= sc; }
+                    V3 dl = (ln - C.ln) * C.n + (l1 - C.l1) * t1 + (l2 - C.l2) * t2;
+                    C.ln = ln; C.l1 = l1; C.l2 = l2;
+                    Sv f = {cross(C.P, dl), dl};
+                    if (is_base) fb = fb + f;
+                    else {
+#pragma unroll
+                        for (int k = 0; k < J; ++k)
+                            if (jl == k) fimp[k] = fimp[k] + f;
+                    }
+                }
+            }
+            float ui[J];
+            Sv run = sv_zero();
+#pragma unroll
+            for (int k = J - 1; k >= 0; --k) {
+                Sv cur = run - fimp[k];
+                ui[k] = -sdot(S[k], cur);
+                run = cur + (ui[k] / D[k]) * U[k];
+            }
+            Sv pAi0 = leg_sum<L>(run - fb);
+            Sv dv = -1.0f * mul6(I0inv, pAi0);
+            velf0 = velf0 + dv;
+#pragma unroll
+            for (int k = 0; k < J; ++k) {
+                float dq = (ui[k] - sdot(U[k], dv)) / D[k];
+                dv = dv + dq * S[k];
+                velf[k] = velf[k] + dv;
+                qdf[k] += dq;
+            }
+        }
+    }
+
+    // ---- contact forces out (world frame, N)
+#pragma unroll
+    for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) {
+        V3 f = {0.f, 0.f, 0.f};
+        const Contact &C = ct[s];
+        if (C.active) {
+            V3 t1, t2;
+            tangents(C.n, t1, t2);
+            f = (1.0f / dt) * mul(Rb, C.ln * C.n + C.l1 * t1 + C.l2 * t2);
+        }
+        if (s == LG_MAX_LEG_SLOTS) fbase = f; else fslot[s] = f;
+    }
+    if (!ok) return;                                        // degenerate model: leave the state untouched
+    // ---- integrate
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float v = qdf[j];
+        float vl = m.vel_limit[d0 + j];
+        if (vl > 0.0f) v = fminf(fmaxf(v, -vl), vl);
+        qd[j] = v;
+        q[j] += dt * v;
+    }
+    V3 wn = velf0.w;
+    V3 vn = velf0.v + dt * cross(wb, vb);
+    V3 vw = mul(Rb, vn), ww = mul(Rb, wn);
+    root[0] += dt * vw.x; root[1] += dt * vw.y; root[2] += dt * vw.z;
+    root[7] = vw.x; root[8] = vw.y; root[9] = vw.z;
+    root[10] = ww.x; root[11] = ww.y; root[12] = ww.z;
+    float ang = sqrtf(dot(wn, wn)) * dt;
+    float sh, ch = cosf(0.5f * ang);
+    V3 ax;
+    if (ang > 1e-8f) { sh = sinf(0.5f * ang); ax = (dt / ang) * wn; } else { sh = 0.5f * dt; ax = wn; }
+    float dq[4] = {sh * ax.x, sh * ax.y, sh * ax.z, ch};
+    float *qq = root + 3;
+    float qn[4] = {qq[3] * dq[0] + qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1],
+                   qq[3] * dq[1] - qq[0] * dq[2] + qq[1] * dq[3] + qq[2] * dq[0],
+                   qq[3] * dq[2] + qq[0] * dq[1] - qq[1] * dq[0] + qq[2] * dq[3],
+                   qq[3] * dq[3] - qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2]};
+    float nrm = 1.0f / sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qq[k] = qn[k] * nrm;
+}

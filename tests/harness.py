@@ -206,3 +206,52 @@ def replay_fixture(env, z, meta, torque_tol=None, report=None):
             np.testing.assert_allclose(env.get("lstm_c"), z[p + "post_lstm_c"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_c")
         if report is not None:
             report.append((t, float(np.abs(env.get("obs") - z[p + "obs"]).max())))
+
+
+class HipHandle:
+    """Adapter giving the HIP context (legged_gym_dev_amd.lib.HipEnvCore) the get/set/call
+    interface of oracle_lib.OracleEnv; every call goes through the C-ABI of liblegged_hip.so."""
+
+    def __init__(self, setup, height_samples=None, device="cuda:0"):
+        import torch
+        from legged_gym_dev_amd.lib import HipEnvCore
+        self.torch = torch
+        self.core = HipEnvCore(setup, height_samples, device)
+        self.setup = setup
+        self._act = None
+
+    def get(self, name):
+        self.torch.cuda.synchronize()
+        return self.core.t[name].cpu().numpy()
+
+    def set(self, name, value):
+        t = self.core.t[name]
+        v = self.torch.as_tensor(np.ascontiguousarray(np.asarray(value)).reshape(tuple(t.shape)))
+        t.copy_(v.to(t.dtype))
+
+    def call(self, fn, *args):
+        self.core.call(fn, *args)
+
+    def set_actions(self, actions):
+        import ctypes as C
+        self._act = self.torch.as_tensor(np.ascontiguousarray(actions, np.float32)).to(self.core.device)
+        self.core.call("set_actions", C.c_void_p(self._act.data_ptr()))
+
+    def step(self, actions):
+        self._act = self.torch.as_tensor(np.ascontiguousarray(actions, np.float32)).to(self.core.device)
+        self.core.step(self._act)
+
+    def set_step_counter(self, v):
+        self.core.lib.lg_set_step_counter(self.core.ctx, int(v))
+
+    def set_init_done(self, v):
+        self.core.lib.lg_set_init_done(self.core.ctx, int(v))
+
+    def inject(self, enable):
+        self.core.lib.lg_inject_uniforms(self.core.ctx, int(enable))
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        self.core.close()
