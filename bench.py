@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the full PPO iteration (24-step rollout of the HIP env +
+HIP PPO update), ANYmal-C flat, 4096 envs per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one PPO iteration: num_steps_per_env(24) x num_envs env steps (each = 4 physics
+substeps + actuator net + post-physics logic) followed by 5 epochs x 4 minibatches of PPO.
+value = 24 * num_envs * n_gpus / mean iteration time  (rsl_rl's fps definition).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
+BYTES_PER_ENV_STEP = 4200.0    # flat ANYmal, fused-step algorithmic bytes
+
+
+def macs_per_sample(obs, hidden, actions):
+    dims_a = [obs] + hidden + [actions]
+    dims_c = [obs] + hidden + [1]
+    return sum(a * b for a, b in zip(dims_a[:-1], dims_a[1:])) + sum(a * b for a, b in zip(dims_c[:-1], dims_c[1:]))
+
+
+def make_runner(num_envs, hidden, device, rank, world):
+    from legged_gym_dev_amd.envs import task_registry  # noqa: F401  (registers tasks)
+    from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
+    from legged_gym_dev_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+    from legged_gym_dev_amd.envs.anymal_c.anymal import Anymal
+    from legged_gym_dev_amd.rl.runner import OnPolicyRunner
+    env_cfg, train_cfg = AnymalCFlatCfg(), AnymalCFlatCfgPPO()
+    env_cfg.env.num_envs = num_envs
+    env_cfg.seed = 1
+    train_cfg.policy.actor_hidden_dims = list(hidden)
+    train_cfg.policy.critic_hidden_dims = list(hidden)
+    args = get_args([])
+    args.sim_device = args.rl_device = device
+    torch.manual_seed(1)
+    import numpy as np
+    np.random.seed(1)
+    sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
+    kw = {"rank": rank, "world_size": world} if world > 1 else {}
+    env = Anymal(env_cfg, sim_params, args.physics_engine, device, True, **kw)
+    runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device=device)
+    return env, runner
+
+
+def time_iterations(runner, steps, warmup, world):
+    ar = runner._all_reduce if world > 1 else None
+    for _ in range(warmup):
+        runner.rollout()
+        runner.ppo.update(ar)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_roll = 0.0
+    for _ in range(steps):
+        a = time.perf_counter()
+        runner.rollout()
+        torch.cuda.synchronize()
+        t_roll += time.perf_counter() - a
+        runner.ppo.update(ar)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el, t_roll], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el, t_roll = float(t[0]), float(t[1])
+    return el, t_roll
+
+
+def gemm_roofline(runner, hidden, reps=8):
+    """fp32-MFMA GEMM group of one minibatch (forward + backward of actor and critic), timed live
+    with HIP events on the launch stream; algorithmic FLOPs = 2 * MACs * rows * 3."""
+    ppo = runner.ppo
+    R = ppo.T * ppo.N // ppo.cfg.num_mini_batches
+    ppo._call("begin_update")
+    ppo._call("minibatch_backward", 0, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(reps):
+        ppo._call("minibatch_backward", 0, k % ppo.cfg.num_mini_batches)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ppo._call("end_update")
+    flops = 2.0 * macs_per_sample(ppo.O, list(hidden), ppo.A) * R * 3.0
+    n_launch = (len(hidden) + 1) * 3 - 1          # fwd + dW per layer, dX for all but the first (actor+critic batched on grid.z)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_gemm<fp32 mfma_32x32x2> (ActorCritic fwd+bwd of one minibatch)",
+            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
+            "traffic": None, "flops_per_minibatch": flops, "ms_per_minibatch": round(ms, 4), "gemm_launches": n_launch}
+
+
+def env_roofline(env, reps=50):
+    a = torch.zeros(env.num_envs, env.num_actions, device=env.device)
+    env.step(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        env.core.step(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gbs = BYTES_PER_ENV_STEP * env.num_envs / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "lg_step (4 x {torque, physics} + post-step)", "achieved": round(gbs, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+            "us_per_env_step_call": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(num_envs, hidden):
+    """Own CPU restatement (oracle/: C++ env step with OpenMP + torch PPO), one bounded sample:
+    a 24-step rollout on `num_envs` envs plus one epoch (4 minibatches) of the update, scaled to the
+    5-epoch iteration.  kind = "port": PhysX / rsl_rl are absent, this is not the reference's CPU path."""
+    import numpy as np
+    from oracle import oracle_lib, ppo_torch
+    from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
+    from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+    from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = AnymalCFlatCfg()
+    cfg.env.num_envs = num_envs
+    cm = compile_model(resolve_model("", "anymal_c"))
+    env = oracle_lib.OracleEnv(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), seed=1))
+    env.call("reset_all")
+    T, A, O = 24, 12, 48
+    ac = ppo_torch.ActorCritic(O, O, A, hidden, hidden)
+    algo = ppo_torch.PPO(ac)
+    obs_buf = torch.zeros(T, num_envs, O)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t in range(T):
+            obs = torch.from_numpy(env.buf["obs"])
+            obs_buf[t] = obs
+            act = ac.act(obs)
+            ac.evaluate(obs)
+            env.step(act.numpy())
+    t_roll = time.perf_counter() - t0
+    R = T * num_envs // 4
+    flat = obs_buf.reshape(T * num_envs, O)
+    t0 = time.perf_counter()
+    for mb in range(4):
+        idx = torch.arange(mb * R, (mb + 1) * R)
+        o = flat[idx]
+        with torch.no_grad():
+            mu = ac.actor(o)
+        algo.step_minibatch(o, o, mu + 0.1, torch.zeros(R, 1), torch.randn(R, 1), torch.randn(R, 1),
+                            torch.zeros(R, 1), mu, torch.ones(R, A))
+    t_epoch = time.perf_counter() - t0
+    env.close()
+    total = t_roll + 5 * t_epoch
+    return {"value": round(T * num_envs / total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 rollout (24 steps x {num_envs} envs, oracle C++/OpenMP env + torch policy) measured {t_roll:.2f}s; "
+                      f"1 of 5 update epochs measured {t_epoch:.2f}s and scaled x5"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--hidden", type=str, default="512,256,128")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+    hidden = [int(v) for v in args.hidden.split(",")]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+    env, runner = make_runner(args.num_envs, hidden, device, rank, world)
+    el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
+    steps_per_iter = runner.num_steps_per_env * args.num_envs * world
+    out = {"metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
+           "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"anymal_c_flat, {args.num_envs} envs/GPU, 24 env steps/iter (decimation 4, actuator LSTM, "
+                                  f"ABA+contact), PPO 5 epochs x 4 minibatches, ActorCritic {hidden}",
+                      "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden, "parallelism": f"env-shard x{world}",
+                      "rollout_ms": round(1e3 * t_roll / args.steps, 3),
+                      "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
+    if rank == 0 and world == 1:
+        out["roofline"] = gemm_roofline(runner, hidden)
+        out["roofline_env_step"] = env_roofline(env)
+        if tuple(hidden) != (128, 64, 32):
+            env.close()
+            runner.ppo.close()
+            env2, runner2 = make_runner(args.num_envs, [128, 64, 32], device, rank, world)
+            el2, tr2 = time_iterations(runner2, max(3, args.steps // 2), 2, world)
+            n2 = max(3, args.steps // 2)
+            out["alt_reference_policy_dims"] = {"policy_hidden": [128, 64, 32], "value": round(steps_per_iter * n2 / el2, 1),
+                                                "ms_per_step": round(1e3 * el2 / n2, 3), "rollout_ms": round(1e3 * tr2 / n2, 3)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.num_envs, hidden)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -188,6 +188,8 @@ typedef struct lg_ppo_buffers {
     float *noise;                                  /* (N, A) injected N(0,1) for act(), or unused */
     int32_t *perm;                                 /* minibatch permutation (T*N) */
     float *adv_partial;                            /* [sum, sumsq, count] for cross-rank normalisation */
+    float *cur_reward_sum, *cur_episode_len;       /* (N) running episode return / length (runner logging) */
+    float *ep_stats;                               /* [sum return, sum length, count] of episodes finished since cleared */
     int64_t num_params, num_reduce;                /* floats to all-reduce per optimiser step */
 } lg_ppo_buffers;
 

@@ -124,6 +124,7 @@ class lg_ppo_buffers(C.Structure):
         ("advantages", PF), ("log_prob", PF), ("mu", PF), ("sigma", PF), ("dones", PU8),
         ("act_actions", PF), ("act_values", PF), ("act_log_prob", PF), ("act_mu", PF),
         ("stats", PF), ("noise", PF), ("perm", PI32), ("adv_partial", PF),
+        ("cur_reward_sum", PF), ("cur_episode_len", PF), ("ep_stats", PF),
         ("num_params", i64), ("num_reduce", i64)]
 
 

@@ -1,0 +1,317 @@
+// C-ABI (include/legged_hip.h, lg_ppo_*) for the PPO learner: parameter/storage allocation in
+// HBM, layer-by-layer GEMM scheduling of the ActorCritic forward/backward, update orchestration.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ppo_device.h"
+
+void lg_set_error(const std::string &s);
+
+extern "C" {
+void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s);
+void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s);
+void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s);
+void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
+                     int64_t cnt, int inject, hipStream_t s);
+void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, const uint8_t *tos, int t, hipStream_t s);
+void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s);
+void ppok_adv_normalize(const PpoDev *P, hipStream_t s);
+void ppok_gather(const PpoDev *P, int mb, hipStream_t s);
+void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s);
+void ppok_step(const PpoDev *P, hipStream_t s);
+}
+
+struct Net {
+    int nl;                                  // linear layers (hidden + head)
+    int dims[LG_PPO_MAX_LAYERS + 1];         // dims[0] = input, dims[nl] = output
+    int64_t w_off[LG_PPO_MAX_LAYERS], b_off[LG_PPO_MAX_LAYERS];
+    float *act[LG_PPO_MAX_LAYERS + 1];       // act[l], l >= 1: output of layer l-1 (workspace, Mmax rows)
+    float *dz[LG_PPO_MAX_LAYERS + 1];        // gradient wrt act[l] pre-activation
+};
+
+struct lg_ppo {
+    lg_ppo_cfg cfg;
+    PpoDev dev;
+    Net net[2];                              // 0 actor, 1 critic
+    hipStream_t stream;
+    int step, inject;
+    int64_t act_count, update_count;
+    int Mmax;
+    std::vector<void *> allocs;
+    std::vector<int32_t> perm_host;
+    uint64_t perm_state;
+    lg_ppo_buffers pub;
+};
+
+template <typename T>
+static bool palloc(lg_ppo *p, T **out, size_t n) {
+    void *q = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    if (hipMalloc(&q, bytes) != hipSuccess || hipMemset(q, 0, bytes) != hipSuccess) return false;
+    p->allocs.push_back(q);
+    *out = (T *)q;
+    return true;
+}
+#define PA(ptr, n) do { if (!palloc(p, &(ptr), (n))) { lg_set_error("hipMalloc failed in lg_ppo_create"); lg_ppo_destroy(p); return -100; } } while (0)
+
+static int launch_ok() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { lg_set_error(std::string("ppo kernel launch: ") + hipGetErrorString(e)); return -100; }
+    return 0;
+}
+
+// forward of the selected nets on M rows.  in[z] = input of net z.  mask bit z selects the net.
+static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask) {
+    const float *in[2] = {in0, in1};
+    int sel[2], nz = 0;
+    for (int z = 0; z < 2; ++z) if (mask & (1 << z)) sel[nz++] = z;
+    const int nl = p->net[sel[0]].nl;
+    for (int l = 0; l < nl; ++l) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        for (int k = 0; k < nz; ++k) {
+            Net &n = p->net[sel[k]];
+            g.A[k] = l == 0 ? in[sel[k]] : n.act[l];
+            g.B[k] = p->dev.params + n.w_off[l];
+            g.bias[k] = p->dev.params + n.b_off[l];
+            g.C[k] = n.act[l + 1];
+            g.M[k] = M; g.N[k] = n.dims[l + 1]; g.K[k] = n.dims[l];
+            g.lda[k] = n.dims[l]; g.ldb[k] = n.dims[l]; g.ldc[k] = n.dims[l + 1];
+        }
+        g.elu = l < nl - 1;
+        ppok_gemm_fwd(&g, nz, p->stream);
+    }
+}
+
+// backward of both nets on M rows given dz[nl] (head output gradients) already filled
+static void backward(lg_ppo *p, int M, const float *in0, const float *in1) {
+    const float *in[2] = {in0, in1};
+    const int nl = p->net[0].nl;
+    for (int l = nl - 1; l >= 0; --l) {
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        long tiles = 0;
+        for (int z = 0; z < 2; ++z) {                // dW_l += dz[l+1]^T . act[l]
+            Net &n = p->net[z];
+            g.A[z] = n.dz[l + 1]; g.lda[z] = n.dims[l + 1];
+            g.B[z] = l == 0 ? in[z] : n.act[l]; g.ldb[z] = n.dims[l];
+            g.C[z] = p->dev.grads + n.w_off[l]; g.ldc[z] = n.dims[l];
+            g.M[z] = n.dims[l + 1]; g.N[z] = n.dims[l]; g.K[z] = M;
+            long t = (long)((g.M[z] + 63) / 64) * ((g.N[z] + 63) / 64);
+            tiles = t > tiles ? t : tiles;
+        }
+        int splits = (int)((1024 + tiles - 1) / tiles);
+        int max_splits = M / 128 > 0 ? M / 128 : 1;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        ppok_gemm_dw(&g, 2, splits, p->stream);
+        if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * ELU'(act[l]); db_{l-1} = colsum(dz[l])
+            memset(&g, 0, sizeof(g));
+            for (int z = 0; z < 2; ++z) {
+                Net &n = p->net[z];
+                g.A[z] = n.dz[l + 1]; g.lda[z] = n.dims[l + 1];
+                g.B[z] = p->dev.params + n.w_off[l]; g.ldb[z] = n.dims[l];
+                g.C[z] = n.dz[l]; g.ldc[z] = n.dims[l];
+                g.aux[z] = n.act[l]; g.ldaux[z] = n.dims[l];
+                g.colsum[z] = p->dev.grads + n.b_off[l - 1];
+                g.M[z] = M; g.N[z] = n.dims[l]; g.K[z] = n.dims[l + 1];
+            }
+            ppok_gemm_dx(&g, 2, p->stream);
+        }
+    }
+}
+
+extern "C" {
+
+int lg_ppo_destroy(lg_ppo *p) {
+    if (!p) return 0;
+    for (void *q : p->allocs) (void)hipFree(q);
+    delete p;
+    return 0;
+}
+
+int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
+    if (!cfg || !out) { lg_set_error("null argument"); return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { lg_set_error("no HIP device: no CPU fallback"); return -2; }
+    if (cfg->activation != 0) { lg_set_error("only activation='elu' is implemented"); return -3; }
+    if (cfg->num_hidden < 1 || cfg->num_hidden > LG_MAX_HIDDEN || cfg->num_actions > LG_PPO_MAX_A) {
+        lg_set_error("unsupported network size"); return -4;
+    }
+    const int N = cfg->num_envs, T = cfg->num_steps, A = cfg->num_actions, O = cfg->num_obs;
+    const int OC = cfg->num_critic_obs > 0 ? cfg->num_critic_obs : O;
+    if ((long)N * T % cfg->num_mini_batches != 0 && (long)N * T / cfg->num_mini_batches == 0) { lg_set_error("bad minibatch count"); return -5; }
+    lg_ppo *p = new lg_ppo();
+    p->cfg = *cfg;
+    p->stream = nullptr;
+    p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0;
+    p->perm_state = cfg->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    const int R = (int)((long)N * T / cfg->num_mini_batches);
+    p->Mmax = R > N ? R : N;
+
+    // parameter layout: std, actor (W,b)*, critic (W,b)*  -- the order of ActorCritic.parameters()
+    int64_t off = 0;
+    PpoDev &d = p->dev;
+    memset(&d, 0, sizeof(d));
+    d.off_std = (int)off; off += A;
+    for (int z = 0; z < 2; ++z) {
+        Net &n = p->net[z];
+        n.nl = cfg->num_hidden + 1;
+        n.dims[0] = z == 0 ? O : OC;
+        for (int l = 0; l < cfg->num_hidden; ++l) n.dims[l + 1] = z == 0 ? cfg->actor_hidden[l] : cfg->critic_hidden[l];
+        n.dims[n.nl] = z == 0 ? A : 1;
+        for (int l = 0; l < n.nl; ++l) {
+            n.w_off[l] = off; off += (int64_t)n.dims[l + 1] * n.dims[l];
+            n.b_off[l] = off; off += n.dims[l + 1];
+        }
+    }
+    d.num_params = off;
+    d.off_bias_actor_head = (int)p->net[0].b_off[p->net[0].nl - 1];
+    d.off_bias_critic_head = (int)p->net[1].b_off[p->net[1].nl - 1];
+    d.N = N; d.T = T; d.A = A; d.O = O; d.OC = OC; d.mb_rows = R;
+    d.world = cfg->world_size > 0 ? cfg->world_size : 1;
+    d.env_offset = 0;
+    d.adaptive = cfg->adaptive_schedule; d.clipped_value = cfg->use_clipped_value_loss;
+    d.seed = cfg->seed;
+    d.gamma = cfg->gamma; d.lam = cfg->lam; d.clip = cfg->clip_param; d.value_coef = cfg->value_loss_coef;
+    d.entropy_coef = cfg->entropy_coef; d.desired_kl = cfg->desired_kl; d.max_grad_norm = cfg->max_grad_norm;
+
+    PA(d.params, off + 2); PA(d.grads, off + 2); PA(d.adam_m, off + 2); PA(d.adam_v, off + 2);
+    const size_t TN = (size_t)T * N;
+    PA(d.st_obs, TN * O);
+    if (cfg->num_critic_obs > 0) PA(d.st_critic_obs, TN * OC); else d.st_critic_obs = d.st_obs;
+    PA(d.st_actions, TN * A); PA(d.st_rewards, TN); PA(d.st_values, TN); PA(d.st_returns, TN); PA(d.st_adv, TN);
+    PA(d.st_log_prob, TN); PA(d.st_mu, TN * A); PA(d.st_sigma, A); PA(d.st_dones, TN);
+    PA(d.act_actions, (size_t)N * A); PA(d.act_values, N); PA(d.act_log_prob, N); PA(d.act_mu, (size_t)N * A);
+    PA(d.stats, 8); PA(d.loss_acc, 4); PA(d.noise, (size_t)N * A); PA(d.perm, TN); PA(d.adv_partial, 4);
+    PA(d.mb_obs, (size_t)R * O);
+    if (cfg->num_critic_obs > 0) PA(d.mb_critic_obs, (size_t)R * OC); else d.mb_critic_obs = d.mb_obs;
+    PA(d.mb_actions, (size_t)R * A); PA(d.mb_mu, (size_t)R * A); PA(d.mb_scalars, (size_t)R * 4);
+    PA(d.cur_reward_sum, N); PA(d.cur_episode_len, N); PA(d.ep_stats, 4);
+    for (int z = 0; z < 2; ++z) {
+        Net &n = p->net[z];
+        n.act[0] = nullptr; n.dz[0] = nullptr;
+        for (int l = 1; l <= n.nl; ++l) { PA(n.act[l], (size_t)p->Mmax * n.dims[l]); PA(n.dz[l], (size_t)p->Mmax * n.dims[l]); }
+    }
+    {   // std = init_noise_std, lr = learning_rate
+        std::vector<float> h(A, cfg->init_noise_std);
+        (void)hipMemcpy(d.params + d.off_std, h.data(), sizeof(float) * A, hipMemcpyHostToDevice);
+        float lr = cfg->learning_rate;
+        (void)hipMemcpy(d.stats, &lr, sizeof(float), hipMemcpyHostToDevice);
+    }
+    p->perm_host.resize(TN);
+    lg_ppo_buffers &b = p->pub;
+    memset(&b, 0, sizeof(b));
+    b.params = d.params; b.grads = d.grads; b.adam_m = d.adam_m; b.adam_v = d.adam_v;
+    b.obs = d.st_obs; b.critic_obs = d.st_critic_obs; b.actions = d.st_actions; b.rewards = d.st_rewards;
+    b.values = d.st_values; b.returns = d.st_returns; b.advantages = d.st_adv; b.log_prob = d.st_log_prob;
+    b.mu = d.st_mu; b.sigma = d.st_sigma; b.dones = d.st_dones;
+    b.act_actions = d.act_actions; b.act_values = d.act_values; b.act_log_prob = d.act_log_prob; b.act_mu = d.act_mu;
+    b.stats = d.stats; b.noise = d.noise; b.perm = d.perm; b.adv_partial = d.adv_partial;
+    b.cur_reward_sum = d.cur_reward_sum; b.cur_episode_len = d.cur_episode_len; b.ep_stats = d.ep_stats;
+    b.num_params = off; b.num_reduce = off + 2;
+    if (hipDeviceSynchronize() != hipSuccess) { lg_set_error("device sync failed in lg_ppo_create"); lg_ppo_destroy(p); return -100; }
+    *out = p;
+    return 0;
+}
+
+int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out) { *out = p->pub; return 0; }
+int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0; }
+int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
+
+// entries: std, then per net per layer (W, b).  offsets[i]; shapes[2i] = rows, shapes[2i+1] = cols (0 for vectors)
+int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_entries) {
+    int k = 0;
+    auto put = [&](int64_t o, int64_t r, int64_t c) {
+        if (k < max_entries) { offsets[k] = o; shapes[2 * k] = r; shapes[2 * k + 1] = c; }
+        ++k;
+    };
+    put(p->dev.off_std, p->cfg.num_actions, 0);
+    for (int z = 0; z < 2; ++z)
+        for (int l = 0; l < p->net[z].nl; ++l) {
+            put(p->net[z].w_off[l], p->net[z].dims[l + 1], p->net[z].dims[l]);
+            put(p->net[z].b_off[l], p->net[z].dims[l + 1], 0);
+        }
+    return k;
+}
+
+int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
+    if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
+    const float *cobs = critic_obs ? critic_obs : obs;
+    forward(p, p->cfg.num_envs, obs, cobs, 3);
+    ppok_act_sample(&p->dev, obs, cobs, p->net[0].act[p->net[0].nl], p->net[1].act[p->net[1].nl], p->step, p->act_count,
+                    p->inject, p->stream);
+    p->act_count++;
+    return launch_ok();
+}
+
+int lg_ppo_process_env_step(lg_ppo *p, const float *rew, const uint8_t *dones, const uint8_t *time_outs) {
+    if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
+    ppok_process_step(&p->dev, rew, dones, time_outs, p->step, p->stream);
+    p->step++;
+    return launch_ok();
+}
+
+int lg_ppo_compute_returns(lg_ppo *p, const float *last_critic_obs) {
+    forward(p, p->cfg.num_envs, nullptr, last_critic_obs, 2);
+    ppok_gae(&p->dev, p->net[1].act[p->net[1].nl], p->stream);
+    return launch_ok();
+}
+
+int lg_ppo_normalize_advantages(lg_ppo *p) {
+    ppok_adv_normalize(&p->dev, p->stream);
+    return launch_ok();
+}
+
+int lg_ppo_begin_update(lg_ppo *p) {
+    // randperm(num_mini_batches * mini_batch_size), drawn once per update (Appendix B)
+    const size_t n = (size_t)p->dev.mb_rows * p->cfg.num_mini_batches;
+    for (size_t i = 0; i < n; ++i) p->perm_host[i] = (int32_t)i;
+    uint64_t s = p->perm_state;
+    for (size_t i = n - 1; i > 0; --i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        size_t j = (size_t)(s % (i + 1));
+        int32_t t = p->perm_host[i]; p->perm_host[i] = p->perm_host[j]; p->perm_host[j] = t;
+    }
+    p->perm_state = s;
+    if (hipMemcpyAsync(p->dev.perm, p->perm_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->stream) != hipSuccess) {
+        lg_set_error("perm upload failed"); return -100;
+    }
+    (void)hipMemsetAsync(p->dev.stats + 2, 0, 2 * sizeof(float), p->stream);
+    (void)hipMemsetAsync(p->dev.stats + 5, 0, sizeof(float), p->stream);
+    (void)hipMemsetAsync(p->dev.loss_acc, 0, 4 * sizeof(float), p->stream);
+    return 0;
+}
+
+int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
+    (void)epoch;
+    PpoDev &d = p->dev;
+    const int R = d.mb_rows;
+    (void)hipMemsetAsync(d.grads, 0, (size_t)(d.num_params + 2) * sizeof(float), p->stream);
+    ppok_gather(&d, mb, p->stream);
+    forward(p, R, d.mb_obs, d.mb_critic_obs, 3);
+    Net &na = p->net[0], &nc = p->net[1];
+    ppok_loss(&d, na.act[na.nl], nc.act[nc.nl], na.dz[na.nl], nc.dz[nc.nl], p->stream);
+    backward(p, R, d.mb_obs, d.mb_critic_obs);
+    return launch_ok();
+}
+
+int lg_ppo_minibatch_step(lg_ppo *p) {
+    ppok_step(&p->dev, p->stream);
+    p->update_count++;
+    return launch_ok();
+}
+
+int lg_ppo_end_update(lg_ppo *p) { p->step = 0; return 0; }
+
+int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows) {
+    if (rows > p->Mmax) { lg_set_error("too many rows for act_inference"); return -11; }
+    forward(p, (int)rows, obs, nullptr, 1);
+    Net &na = p->net[0];
+    if (hipMemcpyAsync(actions_out, na.act[na.nl], (size_t)rows * p->cfg.num_actions * sizeof(float), hipMemcpyDeviceToDevice,
+                       p->stream) != hipSuccess) { lg_set_error("copy failed"); return -100; }
+    return launch_ok();
+}
+
+}  // extern "C"

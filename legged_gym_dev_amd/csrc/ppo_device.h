@@ -1,0 +1,33 @@
+// Device-side structs for the PPO kernels.
+#pragma once
+#include "lg_device.h"
+
+#define LG_PPO_MAX_A 16
+#define LG_PPO_MAX_LAYERS (LG_MAX_HIDDEN + 1)
+
+struct GemmArgs {                  // up to 2 problems per launch (actor, critic) on blockIdx.z
+    const float *A[2], *B[2], *bias[2], *aux[2];
+    float *C[2], *colsum[2];
+    int M[2], N[2], K[2], lda[2], ldb[2], ldc[2], ldaux[2];
+    int elu;
+};
+
+struct PpoDev {                    // passed by value to kernels
+    int N, T, A, O, OC, mb_rows, world, env_offset;
+    int adaptive, clipped_value;
+    uint64_t seed;
+    float gamma, lam, clip, value_coef, entropy_coef, desired_kl, max_grad_norm;
+    int64_t num_params;
+    int off_std, off_bias_actor_head, off_bias_critic_head;
+    float *params, *grads, *adam_m, *adam_v;
+    float *st_obs, *st_critic_obs, *st_actions, *st_rewards, *st_values, *st_returns, *st_adv, *st_log_prob, *st_mu, *st_sigma;
+    uint8_t *st_dones;
+    float *act_actions, *act_values, *act_log_prob, *act_mu;
+    float *stats;                  // [lr, kl, value_loss_sum, surrogate_sum, adam_t, n_updates, adv_mean, adv_std]
+    float *loss_acc;               // [value_loss, surrogate, grad_norm_sq]
+    float *noise;
+    int32_t *perm;
+    float *adv_partial;
+    float *mb_obs, *mb_critic_obs, *mb_actions, *mb_mu, *mb_scalars;   // minibatch gathers; scalars = [v_old, ret, adv, logp_old]
+    float *cur_reward_sum, *cur_episode_len, *ep_stats;                // per-env running sums; [sum_rew, sum_len, count] of finished episodes
+};

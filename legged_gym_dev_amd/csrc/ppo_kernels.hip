@@ -1,0 +1,487 @@
+// PPO kernels for gfx950: fp32-MFMA GEMMs with fused epilogues (ActorCritic forward/backward),
+// action sampling, GAE scan, PPO loss, grad-norm clip + Adam with the KL-adaptive learning rate
+// kept on the device.  Semantics: rsl_rl v1.0.2 (SURVEY.md Appendix B -- third-party, not in the
+// reference tree; call sites legged_gym/utils/task_registry.py:148-155).
+#include "ppo_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = opA(A) . opB(B), K = reduction length.  A_RC: A stored [m][k] (reduction contiguous),
+// else [k][m].  B_RC: B stored [n][k], else [k][n].  4 waves as 2x2, each TM x TN tiles of 32x32
+// computed with v_mfma_f32_32x32x2_f32 (exact fp32, A/B one VGPR per lane: lane l holds
+// A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]).
+// LDS tiles keep the global layout (so the global->LDS copy is a straight 16-byte move) with a
+// one-float row pad; fragments are ds_read_b32 with lanes on consecutive rows/columns, which is
+// bank-conflict free in both layouts and far below the LDS rate at 64 cycles per fp32 MFMA.
+// EPI 0: C = (acc + bias[n]) then ELU if elu      (forward, nn.Linear + ELU)
+// EPI 1: C = acc * ELU'(aux[m][n]); colsum[n] += sum_m C   (input gradient + bias gradient below)
+// EPI 2: C += acc via float atomics, reduction split over blockIdx.y   (weight gradient)
+#define BK 32
+
+template <bool RC, int ROWS>
+__device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld, int row0, int red0, int nrows, int nred,
+                                           bool vec_ok, float4 (&regs)[ROWS * BK / 4 / 256]) {
+    constexpr int NV = ROWS * BK / 4 / 256;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        int idx = tid + v * 256;
+        int r, c;                       // r: index along the tile's non-contiguous dim, c: float4 along the contiguous one
+        if (RC) { c = idx & (BK / 4 - 1); r = idx / (BK / 4); }
+        else { c = idx & (ROWS / 4 - 1); r = idx / (ROWS / 4); }
+        int grow = RC ? row0 + r : red0 + r;        // global row
+        int gcol = RC ? red0 + 4 * c : row0 + 4 * c;
+        int row_lim = RC ? nrows : nred, col_lim = RC ? nred : nrows;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow < row_lim) {
+            const float *p = src + (size_t)grow * ld + gcol;
+            if (vec_ok && gcol + 3 < col_lim) val = *reinterpret_cast<const float4 *>(p);
+            else {
+                if (gcol < col_lim) val.x = p[0];
+                if (gcol + 1 < col_lim) val.y = p[1];
+                if (gcol + 2 < col_lim) val.z = p[2];
+                if (gcol + 3 < col_lim) val.w = p[3];
+            }
+        }
+        regs[v] = val;
+    }
+}
+template <bool RC, int ROWS>
+__device__ __forceinline__ void stage_store(float *__restrict__ lds, const float4 (&regs)[ROWS * BK / 4 / 256]) {
+    constexpr int NV = ROWS * BK / 4 / 256;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        int idx = tid + v * 256;
+        if (RC) {                       // lds[r][BK+1]
+            int c = idx & (BK / 4 - 1), r = idx / (BK / 4);
+            float *d = lds + r * (BK + 1) + 4 * c;
+            d[0] = regs[v].x; d[1] = regs[v].y; d[2] = regs[v].z; d[3] = regs[v].w;
+        } else {                        // lds[k][ROWS+4]
+            int c = idx & (ROWS / 4 - 1), r = idx / (ROWS / 4);
+            *reinterpret_cast<float4 *>(lds + r * (ROWS + 4) + 4 * c) = regs[v];
+        }
+    }
+}
+template <bool RC, int ROWS>
+__device__ __forceinline__ float frag(const float *__restrict__ lds, int row, int k) {
+    return RC ? lds[row * (BK + 1) + k] : lds[k * (ROWS + 4) + row];
+}
+template <bool RC, int ROWS>
+constexpr int tile_floats() { return RC ? ROWS * (BK + 1) : BK * (ROWS + 4); }
+
+template <bool A_RC, bool B_RC, int EPI, int TM, int TN>
+__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    const int z = blockIdx.z;
+    const int M = g.M[z], N = g.N[z], K = g.K[z];
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    // reduction range of this workgroup (split only used by EPI 2)
+    int k_begin = 0, k_end = K;
+    if (EPI == 2) {
+        int per = ((K + gridDim.y - 1) / gridDim.y + BK - 1) / BK * BK;
+        k_begin = blockIdx.y * per;
+        k_end = min(K, k_begin + per);
+        if (k_begin >= k_end) return;
+    }
+    const float *__restrict__ A = g.A[z];
+    const float *__restrict__ B = g.B[z];
+    const int lda = g.lda[z], ldb = g.ldb[z], ldc = g.ldc[z];
+    const bool a_vec = (lda & 3) == 0 && ((uintptr_t)A & 15) == 0;
+    const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0;
+
+    constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
+    __shared__ float lds[2 * (AF + BF)];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
+    const int li = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[BM * BK / 4 / 256], rb[BN * BK / 4 / 256];
+    stage_load<A_RC, BM>(A, lda, m0, k_begin, M, k_end, a_vec, ra);
+    stage_load<B_RC, BN>(B, ldb, n0, k_begin, N, k_end, b_vec, rb);
+    stage_store<A_RC, BM>(lds, ra);
+    stage_store<B_RC, BN>(lds + AF, rb);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) {
+            stage_load<A_RC, BM>(A, lda, m0, k0 + BK, M, k_end, a_vec, ra);
+            stage_load<B_RC, BN>(B, ldb, n0, k0 + BK, N, k_end, b_vec, rb);
+        }
+        const float *as = lds + cur * (AF + BF), *bs = as + AF;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = frag<A_RC, BM>(as, wm + 32 * a + li, 2 * s + lk);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = frag<B_RC, BN>(bs, wn + 32 * b + li, 2 * s + lk);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            stage_store<A_RC, BM>(lds + (cur ^ 1) * (AF + BF), ra);
+            stage_store<B_RC, BN>(lds + (cur ^ 1) * (AF + BF) + AF, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *__restrict__ C = g.C[z];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn + 32 * b + li;
+        float csum = 0.f;
+        const float bias = (EPI == 0 && g.bias[z] && n < N) ? g.bias[z][n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < M && n < N) {
+                    float v = acc[a][b][r];
+                    if (EPI == 0) {
+                        v += bias;
+                        if (g.elu) v = v > 0.f ? v : expm1f(v);
+                        C[(size_t)m * ldc + n] = v;
+                    } else if (EPI == 1) {
+                        const float act = g.aux[z][(size_t)m * g.ldaux[z] + n];
+                        v *= act > 0.f ? 1.0f : act + 1.0f;
+                        C[(size_t)m * ldc + n] = v;
+                        csum += v;
+                    } else {
+                        atomicAdd(&C[(size_t)m * ldc + n], v);
+                    }
+                }
+            }
+        if (EPI == 1 && g.colsum[z]) {
+            csum += __shfl_xor(csum, 32);
+            if (lk == 0 && n < N) atomicAdd(&g.colsum[z][n], csum);
+        }
+    }
+}
+
+template <bool A_RC, bool B_RC, int EPI>
+static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
+    int maxM = 0, maxN = 0;
+    for (int z = 0; z < nz; ++z) { maxM = g.M[z] > maxM ? g.M[z] : maxM; maxN = g.N[z] > maxN ? g.N[z] : maxN; }
+    // small problems (rollout forward on 4096 rows, heads) use 64x64 tiles to fill more CUs
+    const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
+    if (big_tiles * splits >= 192 && maxN > 64) {
+        dim3 grid((unsigned)big_tiles, splits, nz);
+        hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2>), grid, dim3(256), 0, s, g);
+    } else {
+        dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), splits, nz);
+        hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1>), grid, dim3(256), 0, s, g);
+    }
+}
+extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) { launch_gemm<true, true, 0>(*g, nz, 1, s); }
+extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s) { launch_gemm<true, false, 1>(*g, nz, 1, s); }
+extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s) { launch_gemm<false, false, 2>(*g, nz, splits, s); }
+
+// ------------------------------------------------------------------------------------------------
+// PPO.act epilogue: a ~ N(mu, sigma), log-prob, transition store (rsl_rl PPO.act / storage.add)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t env, uint64_t step, uint32_t a) {
+    uint32_t c[4] = {env, (uint32_t)step, a, 0x5eedu};
+    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
+    float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__global__ void k_act_sample(PpoDev P, const float *__restrict__ obs, const float *__restrict__ critic_obs,
+                             const float *__restrict__ mu, const float *__restrict__ val, int t, int64_t act_count, int inject) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = P.N, A = P.A, O = P.O;
+    if (i >= N) return;
+    const float *std = P.params + P.off_std;
+    float lp = 0.f;
+    for (int a = 0; a < A; ++a) {
+        float m = mu[(size_t)i * A + a], s = std[a];
+        float z = inject ? P.noise[(size_t)i * A + a] : philox_normal(P.seed, (uint32_t)(P.env_offset + i), (uint64_t)act_count, a);
+        float act = m + s * z;
+        lp += -((act - m) * (act - m)) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+        P.act_actions[(size_t)i * A + a] = act;
+        P.act_mu[(size_t)i * A + a] = m;
+        if (t >= 0) {
+            P.st_actions[((size_t)t * N + i) * A + a] = act;
+            P.st_mu[((size_t)t * N + i) * A + a] = m;
+        }
+    }
+    const float v = val[i];
+    P.act_values[i] = v;
+    P.act_log_prob[i] = lp;
+    if (t >= 0) {
+        P.st_values[(size_t)t * N + i] = v;
+        P.st_log_prob[(size_t)t * N + i] = lp;
+        for (int k = 0; k < O; ++k) P.st_obs[((size_t)t * N + i) * O + k] = obs[(size_t)i * O + k];
+        if (P.st_critic_obs != P.st_obs)
+            for (int k = 0; k < P.OC; ++k) P.st_critic_obs[((size_t)t * N + i) * P.OC + k] = critic_obs[(size_t)i * P.OC + k];
+    }
+    if (i < A && t == 0) P.st_sigma[i] = std[i];
+}
+
+// PPO.process_env_step: rewards += gamma * V * time_outs ; store
+__global__ void k_process_step(PpoDev P, const float *__restrict__ rew, const uint8_t *__restrict__ dones,
+                               const uint8_t *__restrict__ time_outs, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.N) return;
+    float r = rew[i];
+    if (time_outs) r += P.gamma * (P.st_values[(size_t)t * P.N + i] * (time_outs[i] ? 1.0f : 0.0f));
+    P.st_rewards[(size_t)t * P.N + i] = r;
+    P.st_dones[(size_t)t * P.N + i] = dones[i] ? 1 : 0;
+    // runner bookkeeping (OnPolicyRunner.learn: cur_reward_sum / cur_episode_length / rewbuffer)
+    const float cr = P.cur_reward_sum[i] + rew[i], cl = P.cur_episode_len[i] + 1.0f;
+    if (dones[i]) {
+        atomicAdd(&P.ep_stats[0], cr);
+        atomicAdd(&P.ep_stats[1], cl);
+        atomicAdd(&P.ep_stats[2], 1.0f);
+        P.cur_reward_sum[i] = 0.f;
+        P.cur_episode_len[i] = 0.f;
+    } else {
+        P.cur_reward_sum[i] = cr;
+        P.cur_episode_len[i] = cl;
+    }
+}
+
+// RolloutStorage.compute_returns: GAE reverse scan, one lane per env; block sums of adv, adv^2
+__global__ void __launch_bounds__(256) k_gae(PpoDev P, const float *__restrict__ last_values) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = P.N, T = P.T;
+    float s1 = 0.f, s2 = 0.f;
+    if (i < N) {
+        float adv = 0.f, next_v = last_values[i];
+        for (int t = T - 1; t >= 0; --t) {
+            const size_t k = (size_t)t * N + i;
+            const float nnt = 1.0f - (P.st_dones[k] ? 1.0f : 0.0f);
+            const float v = P.st_values[k];
+            const float delta = P.st_rewards[k] + nnt * P.gamma * next_v - v;
+            adv = delta + nnt * P.gamma * P.lam * adv;
+            const float ret = adv + v;
+            P.st_returns[k] = ret;
+            const float a = ret - v;
+            P.st_adv[k] = a;
+            s1 += a; s2 += a * a;
+            next_v = v;
+        }
+    }
+    __shared__ float r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { r1[threadIdx.x] += r1[threadIdx.x + w]; r2[threadIdx.x] += r2[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&P.adv_partial[0], r1[0]);
+        atomicAdd(&P.adv_partial[1], r2[0]);
+        if (blockIdx.x == 0) P.adv_partial[2] = (float)((size_t)N * T);
+    }
+}
+// advantages = (adv - mean) / (std_unbiased + 1e-8) over all samples (of all ranks after all-reduce)
+__global__ void k_adv_normalize(PpoDev P) {
+    const size_t n = (size_t)P.N * P.T;
+    const float cnt = P.adv_partial[2], mean = P.adv_partial[0] / cnt;
+    const float var = fmaxf((P.adv_partial[1] - cnt * mean * mean) / fmaxf(cnt - 1.0f, 1.0f), 0.f);
+    const float inv = 1.0f / (sqrtf(var) + 1e-8f);
+    for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+        P.st_adv[k] = (P.st_adv[k] - mean) * inv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { P.stats[6] = mean; P.stats[7] = sqrtf(var); }
+}
+
+// mini_batch_generator: rows perm[mb*R .. (mb+1)*R) of the (T*N)-flattened storage
+__global__ void k_gather(PpoDev P, int mb) {
+    const int R = P.mb_rows, A = P.A, O = P.O;
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const int src = P.perm[(size_t)mb * R + r];
+    for (int k = threadIdx.x; k < O; k += blockDim.x) P.mb_obs[(size_t)r * O + k] = P.st_obs[(size_t)src * O + k];
+    if (P.st_critic_obs != P.st_obs)
+        for (int k = threadIdx.x; k < P.OC; k += blockDim.x) P.mb_critic_obs[(size_t)r * P.OC + k] = P.st_critic_obs[(size_t)src * P.OC + k];
+    if ((int)threadIdx.x < A) {
+        P.mb_actions[(size_t)r * A + threadIdx.x] = P.st_actions[(size_t)src * A + threadIdx.x];
+        P.mb_mu[(size_t)r * A + threadIdx.x] = P.st_mu[(size_t)src * A + threadIdx.x];
+    }
+    if (threadIdx.x == 0) {
+        P.mb_scalars[(size_t)r * 4 + 0] = P.st_values[src];
+        P.mb_scalars[(size_t)r * 4 + 1] = P.st_returns[src];
+        P.mb_scalars[(size_t)r * 4 + 2] = P.st_adv[src];
+        P.mb_scalars[(size_t)r * 4 + 3] = P.st_log_prob[src];
+    }
+}
+
+// PPO.update loss for one minibatch: surrogate, clipped value loss, entropy bonus, KL(old || new);
+// emits d loss / d mu (R x A), d loss / d value (R), and block-reduced d loss / d std, bias grads
+// of both heads and the loss statistics.
+__global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict__ mu_new, const float *__restrict__ v_new,
+                                              float *__restrict__ dmu, float *__restrict__ dval) {
+    const int R = P.mb_rows, A = P.A;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *std = P.params + P.off_std;
+    const float invR = 1.0f / (float)R;
+    // per-thread partials: [0..A) dstd, [A..2A) dbias_actor_head, 2A dbias_critic_head, then kl, vloss, sloss
+    float part[2 * LG_PPO_MAX_A + 4];
+    for (int k = 0; k < 2 * A + 4; ++k) part[k] = 0.f;
+    if (r < R) {
+        const float v_old = P.mb_scalars[(size_t)r * 4 + 0], ret = P.mb_scalars[(size_t)r * 4 + 1];
+        const float adv = P.mb_scalars[(size_t)r * 4 + 2], lp_old = P.mb_scalars[(size_t)r * 4 + 3];
+        float lp = 0.f, kl = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float s = std[a], so = P.st_sigma[a];
+            const float m = mu_new[(size_t)r * A + a], mo = P.mb_mu[(size_t)r * A + a];
+            const float d = P.mb_actions[(size_t)r * A + a] - m;
+            lp += -(d * d) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+            kl += logf(s / so + 1.e-5f) + (so * so + (mo - m) * (mo - m)) / (2.0f * s * s) - 0.5f;
+        }
+        const float ratio = expf(lp - lp_old);
+        const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+        const float s1 = -adv * ratio, s2 = -adv * rc;
+        const float dl_dlp = (s1 >= s2 ? -adv : 0.0f) * ratio * invR;        // torch.max ties: see DESIGN.md
+        for (int a = 0; a < A; ++a) {
+            const float s = std[a];
+            const float d = P.mb_actions[(size_t)r * A + a] - mu_new[(size_t)r * A + a];
+            const float g = dl_dlp * d / (s * s);
+            dmu[(size_t)r * A + a] = g;
+            part[A + a] = g;
+            part[a] = dl_dlp * (d * d / (s * s * s) - 1.0f / s) - P.entropy_coef * invR / s;
+        }
+        const float v = v_new[r];
+        float lv, dv;
+        if (P.clipped_value) {
+            const float dvv = v - v_old;
+            const float vc = v_old + fminf(fmaxf(dvv, -P.clip), P.clip);
+            const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+            const float inside = (dvv >= -P.clip && dvv <= P.clip) ? 1.0f : 0.0f;
+            lv = fmaxf(l1, l2);
+            if (l1 > l2) dv = 2.0f * (v - ret);
+            else if (l1 < l2) dv = 2.0f * (vc - ret) * inside;
+            else dv = (v - ret) + (vc - ret) * inside;
+        } else {
+            lv = (ret - v) * (ret - v);
+            dv = 2.0f * (v - ret);
+        }
+        dv *= P.value_coef * invR;
+        dval[r] = dv;
+        part[2 * A] = dv;
+        part[2 * A + 1] = kl;
+        part[2 * A + 2] = lv;
+        part[2 * A + 3] = fmaxf(s1, s2);
+    }
+    // block reduction of the partial vector through LDS
+    __shared__ float red[256];
+    for (int k = 0; k < 2 * A + 4; ++k) {
+        red[threadIdx.x] = part[k];
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float v = red[0];
+            if (k < A) atomicAdd(&P.grads[P.off_std + k], v);
+            else if (k < 2 * A) atomicAdd(&P.grads[P.off_bias_actor_head + (k - A)], v);
+            else if (k == 2 * A) atomicAdd(&P.grads[P.off_bias_critic_head], v);
+            else if (k == 2 * A + 1) atomicAdd(&P.grads[P.num_params], v);          // KL sum rides in the grad buffer tail
+            else if (k == 2 * A + 2) atomicAdd(&P.loss_acc[0], v);
+            else atomicAdd(&P.loss_acc[1], v);
+        }
+        __syncthreads();
+    }
+}
+
+// KL-adaptive learning rate (rsl_rl PPO.update) + reset of the norm accumulator
+__global__ void k_pre_step(PpoDev P) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float kl = P.grads[P.num_params] / ((float)P.mb_rows * (float)P.world);
+    float lr = P.stats[0];
+    if (P.adaptive) {
+        if (kl > P.desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+        else if (kl < P.desired_kl / 2.0f && kl > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+    }
+    P.stats[0] = lr;
+    P.stats[1] = kl;
+    P.stats[2] += P.loss_acc[0] / (float)P.mb_rows;
+    P.stats[3] += P.loss_acc[1] / (float)P.mb_rows;
+    P.stats[5] += 1.0f;
+    P.loss_acc[0] = 0.f; P.loss_acc[1] = 0.f; P.loss_acc[2] = 0.f;
+}
+__global__ void __launch_bounds__(256) k_grad_norm(PpoDev P) {
+    float s = 0.f;
+    const float inv_world = 1.0f / (float)P.world;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)gridDim.x * blockDim.x) {
+        float g = P.grads[k] * inv_world;
+        s += g * g;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(&P.loss_acc[2], red[0]);
+}
+// clip_grad_norm_(max_norm) + torch.optim.Adam step (betas 0.9/0.999, eps 1e-8)
+__global__ void k_adam(PpoDev P) {
+    const float total = sqrtf(P.loss_acc[2]);
+    const float coef = fminf(P.max_grad_norm / (total + 1e-6f), 1.0f);
+    const float lr = P.stats[0], t = P.stats[4] + 1.0f;
+    const float bc1 = 1.0f - powf(0.9f, t), bc2 = 1.0f - powf(0.999f, t);
+    const float inv_world = 1.0f / (float)P.world;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)gridDim.x * blockDim.x) {
+        const float g = P.grads[k] * inv_world * coef;
+        const float m = 0.9f * P.adam_m[k] + 0.1f * g;
+        const float v = 0.999f * P.adam_v[k] + 0.001f * g * g;
+        P.adam_m[k] = m;
+        P.adam_v[k] = v;
+        P.params[k] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+    }
+}
+__global__ void k_adam_tick(PpoDev P) { if (threadIdx.x == 0 && blockIdx.x == 0) P.stats[4] += 1.0f; }
+
+extern "C" {
+void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
+                     int64_t cnt, int inject, hipStream_t s) {
+    hipLaunchKernelGGL(k_act_sample, dim3((P->N + 63) / 64), dim3(64), 0, s, *P, obs, cobs, mu, val, t, cnt, inject);
+}
+void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, const uint8_t *tos, int t, hipStream_t s) {
+    hipLaunchKernelGGL(k_process_step, dim3((P->N + 255) / 256), dim3(256), 0, s, *P, rew, dones, tos, t);
+}
+void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s) {
+    (void)hipMemsetAsync(P->adv_partial, 0, 3 * sizeof(float), s);
+    hipLaunchKernelGGL(k_gae, dim3((P->N + 255) / 256), dim3(256), 0, s, *P, last_values);
+}
+void ppok_adv_normalize(const PpoDev *P, hipStream_t s) {
+    hipLaunchKernelGGL(k_adv_normalize, dim3(256), dim3(256), 0, s, *P);
+}
+void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather, dim3(P->mb_rows), dim3(64), 0, s, *P, mb);
+}
+void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss, dim3((P->mb_rows + 255) / 256), dim3(256), 0, s, *P, mu, v, dmu, dval);
+}
+void ppok_step(const PpoDev *P, hipStream_t s) {
+    hipLaunchKernelGGL(k_pre_step, dim3(1), dim3(64), 0, s, *P);
+    hipLaunchKernelGGL(k_grad_norm, dim3(128), dim3(256), 0, s, *P);
+    hipLaunchKernelGGL(k_adam, dim3(256), dim3(256), 0, s, *P);
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, *P);
+}
+}

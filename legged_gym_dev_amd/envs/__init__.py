@@ -1,0 +1,12 @@
+"""Task registrations of the hot-path scope (reference: legged_gym/envs/__init__.py:53-54,59)."""
+from legged_gym_dev_amd.utils.task_registry import task_registry
+from .base.legged_robot import LeggedRobot
+from .anymal_c.anymal import Anymal
+from .anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
+from .anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
+from .cassie.cassie import Cassie
+from .cassie.cassie_config import CassieRoughCfg, CassieRoughCfgPPO
+
+task_registry.register("anymal_c_rough", Anymal, AnymalCRoughCfg(), AnymalCRoughCfgPPO())
+task_registry.register("anymal_c_flat", Anymal, AnymalCFlatCfg(), AnymalCFlatCfgPPO())
+task_registry.register("cassie", Cassie, CassieRoughCfg(), CassieRoughCfgPPO())

@@ -1,0 +1,183 @@
+"""VecEnv shim: the reference's ``LeggedRobot`` surface (legged_gym/envs/base/legged_robot.py,
+base_task.py) on top of one ``lg_ctx`` of liblegged_hip.so.
+
+Every attribute the reference exposes as a torch tensor (root_states, dof_pos, contact_forces,
+obs_buf, rew_buf, reset_buf, episode_length_buf, commands, ...) is a zero-copy view of HBM owned by
+the library; ``step()`` is one C-ABI call (lg_step) with no host synchronisation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from legged_gym_dev_amd import LEGGED_GYM_ROOT_DIR, capi
+from legged_gym_dev_amd.lib import HipEnvCore
+from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+from legged_gym_dev_amd.utils.terrain import Terrain
+from .base_task import BaseTask
+from .env_setup import EnvSetup, sim_dt_float
+
+
+def draw_env_constants(cfg, num_envs_total, body0_mass, terrain):
+    """Per-env constants with the reference's draw order on torch's / numpy's global CPU
+    generators (``_get_env_origins`` legged_robot.py:790-817, then per env i of ``_create_envs``
+    :738-751: start-pose jitter rand(2,1); at i == 0 friction buckets randint(0,64,(N,1)) and
+    rand(64,1) (:271-282); base-mass np.random.uniform (:332-334))."""
+    N = num_envs_total
+    out = {}
+    if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+        max_init = cfg.terrain.max_init_terrain_level if cfg.terrain.curriculum else cfg.terrain.num_rows - 1
+        levels = torch.randint(0, max_init + 1, (N,))
+        types = torch.div(torch.arange(N), (N / cfg.terrain.num_cols), rounding_mode="floor").to(torch.long)
+        origins = torch.from_numpy(terrain.env_origins).to(torch.float)[levels, types]
+        out["terrain_levels"], out["terrain_types"] = levels, types
+    else:
+        num_cols = np.floor(np.sqrt(N))
+        num_rows = np.ceil(N / num_cols)
+        xx, yy = torch.meshgrid(torch.arange(num_rows), torch.arange(num_cols), indexing="ij")
+        origins = torch.zeros(N, 3)
+        origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:N]
+        origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:N]
+    out["env_origins"] = origins
+    friction = torch.ones(N)
+    dmass = np.zeros(N, dtype=np.float64)
+    for i in range(N):
+        torch.rand(2, 1)                                   # start-pose jitter (overwritten by the first reset)
+        if cfg.domain_rand.randomize_friction and i == 0:
+            lo, hi = cfg.domain_rand.friction_range
+            bucket_ids = torch.randint(0, 64, (N, 1))
+            buckets = (hi - lo) * torch.rand(64, 1) + lo
+            friction = buckets[bucket_ids].reshape(N)
+        if cfg.domain_rand.randomize_base_mass:
+            lo, hi = cfg.domain_rand.added_mass_range
+            dmass[i] = np.random.uniform(lo, hi)
+    out["friction"] = friction
+    out["base_mass_delta"] = torch.from_numpy((body0_mass + dmass).astype(np.float32) - np.float32(body0_mass))
+    out["base_mass"] = body0_mass + dmass
+    return out
+
+
+class LeggedRobot(BaseTask):
+    def __init__(self, cfg, sim_params, physics_engine, sim_device, headless, rank=0, world_size=1):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.height_samples = None
+        self.debug_viz = False
+        self.init_done = False
+        self.rank, self.world_size = rank, world_size
+        super().__init__(cfg, sim_params, physics_engine, sim_device, headless)
+
+        asset_path = cfg.asset.file.format(LEGGED_GYM_ROOT_DIR=LEGGED_GYM_ROOT_DIR)
+        self.robot_model = resolve_model(asset_path, cfg.asset.name, cfg.asset.collapse_fixed_joints,
+                                         cfg.asset.replace_cylinder_with_capsule)
+        cm = compile_model(self.robot_model)
+        total = self.num_envs * world_size
+        self.terrain = None
+        if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            self.terrain = Terrain(cfg.terrain, total)
+        elif cfg.terrain.mesh_type not in (None, "plane", "none"):
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
+        seed = getattr(cfg, "seed", 1)
+        self.setup = EnvSetup(cfg, cm, sim_dt_float(sim_params.dt), terrain=self.terrain,
+                              env_offset=rank * self.num_envs, total_envs=total, seed=seed)
+        s = self.setup
+        for name in ("dt", "obs_scales", "reward_scales", "command_ranges", "push_time", "max_push_vel",
+                     "max_episode_length_s", "max_episode_length", "num_dof", "num_bodies", "dof_names", "body_names",
+                     "dof_pos_limits", "dof_vel_limits", "torque_limits", "num_height_points", "custom_origins"):
+            setattr(self, name, getattr(s, name))
+        self.num_dofs = self.num_dof
+        body0_mass = float(self.robot_model["bodies"][0]["mass"])
+        consts = draw_env_constants(cfg, total, body0_mass, self.terrain)
+        hs = self.terrain.heightsamples if self.terrain is not None else None
+        self.core = HipEnvCore(s, hs, device=self.device)
+        t = self.core.t
+        lo, hi = rank * self.num_envs, (rank + 1) * self.num_envs
+        t["env_origins"].copy_(consts["env_origins"][lo:hi])
+        t["friction"].copy_(consts["friction"][lo:hi])
+        t["base_mass_delta"].copy_(consts["base_mass_delta"][lo:hi])
+        if "terrain_levels" in consts:
+            t["terrain_levels"].copy_(consts["terrain_levels"][lo:hi])
+            t["terrain_types"].copy_(consts["terrain_types"][lo:hi])
+            self.height_samples = torch.tensor(hs).to(self.device)
+            self.terrain_origins = torch.from_numpy(self.terrain.env_origins).to(self.device).to(torch.float)
+            self.max_terrain_level = cfg.terrain.num_rows
+        self.friction_coeffs = consts["friction"].reshape(-1, 1)
+        self._bind_views()
+        self.common_step_counter = 0
+        self.extras = {}
+        self.init_done = True
+
+    # ------------------------------------------------------------------ tensor surface
+    def _bind_views(self):
+        t, dev = self.core.t, self.device
+        N, A = self.num_envs, self.num_dof
+        self.root_states, self.dof_state = t["root_states"], t["dof_state"].view(N * A, 2)
+        self.dof_pos, self.dof_vel = t["dof_state"][..., 0], t["dof_state"][..., 1]
+        self.base_quat = self.root_states[:, 3:7]
+        self.contact_forces = t["contact_forces"]
+        self.obs_buf, self.rew_buf = t["obs"], t["rew"]
+        self.reset_buf, self.time_out_buf = t["reset"].view(torch.bool), t["time_out"].view(torch.bool)
+        self._episode_length_buf = t["episode_length"]
+        self.torques, self.actions, self.commands = t["torques"], t["actions"], t["commands"]
+        self.last_actions, self.last_dof_vel, self.last_root_vel = t["last_actions"], t["last_dof_vel"], t["last_root_vel"]
+        self.feet_air_time, self.last_contacts = t["feet_air_time"], t["last_contacts"].view(torch.bool)
+        self.base_lin_vel, self.base_ang_vel, self.projected_gravity = t["base_lin_vel"], t["base_ang_vel"], t["projected_gravity"]
+        self.measured_heights = t["measured_heights"] if self.setup.measure_heights else 0
+        self.env_origins = t["env_origins"]
+        if self.custom_origins:
+            self.terrain_levels, self.terrain_types = t["terrain_levels"], t["terrain_types"]
+        s = self.setup
+        self.feet_indices = torch.tensor(s.feet_indices, dtype=torch.long, device=dev)
+        self.penalised_contact_indices = torch.tensor(s.penalised_contact_indices, dtype=torch.long, device=dev)
+        self.termination_contact_indices = torch.tensor(s.termination_contact_indices, dtype=torch.long, device=dev)
+        self.default_dof_pos = torch.tensor(s.default_dof_pos, device=dev).unsqueeze(0)
+        self.p_gains, self.d_gains = torch.tensor(s.p_gains, device=dev), torch.tensor(s.d_gains, device=dev)
+        self.noise_scale_vec = torch.tensor(s.noise_scale_vec, device=dev)
+        self.episode_sums = {k: t["episode_sums"][capi.REWARD_NAMES.index(k)] for k in s.reward_scales}
+        self._extras_episode = {"rew_" + k: t["extras_episode"][capi.REWARD_NAMES.index(k)] for k in s.reward_scales}
+        if bool(self.cfg.terrain.curriculum):
+            self._extras_episode["terrain_level"] = t["extras_terrain_level"][0]
+        self._extras_time_outs = t["extras_time_outs"].view(torch.bool)
+        if self.setup.use_actuator_net:
+            self.sea_hidden_state, self.sea_cell_state = t["lstm_h"], t["lstm_c"]
+            self.sea_hidden_state_per_env = t["lstm_h"].view(2, N, A, 8)
+            self.sea_cell_state_per_env = t["lstm_c"].view(2, N, A, 8)
+
+    @property
+    def episode_length_buf(self):
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):          # the runner assigns to it (init_at_random_ep_len)
+        self._episode_length_buf.copy_(torch.as_tensor(value).to(self.device))
+
+    # ------------------------------------------------------------------ VecEnv API
+    def step(self, actions):
+        a = actions.to(self.device, dtype=torch.float32).contiguous()
+        self.core.step(a)
+        self.common_step_counter += 1
+        self.extras["episode"] = self._extras_episode
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self._extras_time_outs
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset_idx(self, env_ids):
+        n = len(env_ids)
+        if n == 0:
+            return
+        if n != self.num_envs:
+            raise NotImplementedError("reset_idx of an arbitrary subset from Python is not part of the hot path; "
+                                      "resets happen inside lg_step.  Only reset_idx(all envs) is supported.")
+        self.core.lib.lg_set_init_done(self.core.ctx, int(self.init_done))
+        self.core.call("reset_all")
+
+    def post_physics_step(self):
+        self.core.call("post_physics_step")
+        self.common_step_counter += 1
+
+    def compute_observations(self):
+        return self.obs_buf
+
+    def close(self):
+        self.core.close()

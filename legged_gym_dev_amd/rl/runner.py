@@ -1,0 +1,182 @@
+"""OnPolicyRunner with rsl_rl's surface (constructor call site legged_gym/utils/task_registry.py:148,
+``learn`` scripts/train.py:44, ``load/get_inference_policy/alg.actor_critic`` scripts/play.py:70-86),
+driving the HIP env step and the HIP PPO learner.  Semantics per SURVEY.md Appendix B.
+
+Multi-GPU: one process per GPU (torchrun); envs are sharded, the fused [gradients | KL] buffer is
+all-reduced over RCCL once per optimiser step and the advantage moments once per iteration.
+The rollout loop issues only asynchronous C-ABI calls; the host synchronises once per iteration
+(for the timers that define the env-steps/s metric).
+"""
+import os
+import time
+from collections import deque
+
+import torch
+
+from .ppo import HipPPO
+
+
+class _ActorFacade(torch.nn.Module):
+    """`alg.actor_critic.actor(obs)` -> action means (play.py:70-86)."""
+
+    def __init__(self, ppo):
+        super().__init__()
+        self._ppo = ppo
+
+    def forward(self, obs):
+        return self._ppo.act_inference(obs)
+
+
+class ActorCriticFacade:
+    def __init__(self, ppo):
+        self._ppo = ppo
+        self.actor = _ActorFacade(ppo)
+
+    @property
+    def std(self):
+        return self._ppo.param_views["std"]
+
+    def state_dict(self):
+        return self._ppo.state_dict()
+
+    def load_state_dict(self, sd):
+        self._ppo.load_state_dict(sd)
+
+    def act_inference(self, obs):
+        return self._ppo.act_inference(obs)
+
+    def eval(self):
+        return self
+
+    def train(self):
+        return self
+
+    def to(self, device):
+        return self
+
+
+class _Alg:
+    def __init__(self, ppo):
+        self.ppo = ppo
+        self.actor_critic = ActorCriticFacade(ppo)
+
+    @property
+    def learning_rate(self):
+        return self.ppo.learning_rate
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cuda:0", wandb_callback=None):
+        self.cfg = train_cfg["runner"]
+        self.alg_cfg, self.policy_cfg = train_cfg["algorithm"], train_cfg["policy"]
+        self.device = str(device).replace("hip", "cuda")
+        self.env = env
+        self.wandb_callback = wandb_callback
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        if str(torch.device(self.device)) != str(torch.device(env.device)):
+            raise RuntimeError(f"rl_device {self.device} != sim_device {env.device}: the HIP learner consumes the env's "
+                               "HBM buffers in place")
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        ncrit = env.num_privileged_obs if env.num_privileged_obs is not None else env.num_obs
+        self.ppo = HipPPO(env.num_envs, env.num_obs, ncrit, env.num_actions, self.policy_cfg, self.alg_cfg,
+                          self.num_steps_per_env, device=self.device, seed=train_cfg.get("seed", 1),
+                          world_size=self.world_size, rank=self.rank)
+        self.alg = _Alg(self.ppo)
+        if self.world_size > 1:                       # identical initial policy on every rank
+            torch.distributed.broadcast(self.ppo.t["params"], src=0)
+        self.log_dir = log_dir
+        self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
+        self.rewbuffer, self.lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        self.last_fps = 0.0
+        _, _ = self.env.reset()
+
+    def _all_reduce(self, t):
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+
+    # ------------------------------------------------------------------
+    def rollout(self):
+        env, ppo = self.env, self.ppo
+        obs = env.get_observations()
+        for _ in range(self.num_steps_per_env):
+            actions = ppo.act(obs, None)
+            obs, priv, rewards, dones, infos = env.step(actions)
+            ppo.process_env_step(rewards, env.core.t["reset"], {"time_outs": env.core.t["extras_time_outs"]}
+                                 if "time_outs" in infos else {})
+        ppo.compute_returns(obs, self._all_reduce if self.world_size > 1 else None)
+
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        env, ppo = self.env, self.ppo
+        if init_at_random_ep_len:
+            env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            torch.cuda.synchronize()
+            start = time.time()
+            self.rollout()
+            torch.cuda.synchronize()
+            stop = time.time()
+            collection_time = stop - start
+            start = stop
+            mean_value_loss, mean_surrogate_loss = ppo.update(self._all_reduce if self.world_size > 1 else None)
+            torch.cuda.synchronize()
+            learn_time = time.time() - start
+            self._log(it, tot_iter, collection_time, learn_time, float(mean_value_loss), float(mean_surrogate_loss))
+            if self.log_dir is not None and self.rank == 0 and it % self.save_interval == 0:
+                self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None and self.rank == 0:
+            self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
+
+    def _log(self, it, tot_iter, collection_time, learn_time, vloss, sloss, width=80, pad=35):
+        ppo = self.ppo
+        steps = self.num_steps_per_env * self.env.num_envs * self.world_size
+        self.tot_timesteps += steps
+        self.tot_time += collection_time + learn_time
+        fps = int(steps / (collection_time + learn_time))
+        self.last_fps = fps
+        es = ppo.t["ep_stats"].cpu().tolist()
+        ppo.t["ep_stats"].zero_()
+        if es[2] > 0:
+            self.rewbuffer.append(es[0] / es[2])
+            self.lenbuffer.append(es[1] / es[2])
+        mean_std = float(ppo.param_views["std"].mean())
+        ep = {k: float(v) for k, v in self.env.extras.get("episode", {}).items()}
+        if self.rank != 0:
+            return
+        lines = [f" Learning iteration {it}/{tot_iter} ".center(width, " "), "",
+                 f"{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {collection_time:.3f}s, learning {learn_time:.3f}s)",
+                 f"{'Value function loss:':>{pad}} {vloss:.4f}", f"{'Surrogate loss:':>{pad}} {sloss:.4f}",
+                 f"{'Mean action noise std:':>{pad}} {mean_std:.2f}", f"{'Learning rate:':>{pad}} {ppo.learning_rate:.2e}"]
+        if self.rewbuffer:
+            lines += [f"{'Mean reward:':>{pad}} {self.rewbuffer[-1]:.2f}", f"{'Mean episode length:':>{pad}} {self.lenbuffer[-1]:.2f}"]
+        lines += [f"{'Mean episode ' + k + ':':>{pad}} {v:.4f}" for k, v in ep.items()]
+        lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}",
+                  f"{'Iteration time:':>{pad}} {collection_time + learn_time:.2f}s", f"{'Total time:':>{pad}} {self.tot_time:.2f}s"]
+        print("#" * width + "\n" + "\n".join(lines) + "\n", flush=True)
+        if self.wandb_callback is not None:
+            locs = {"mean_value_loss": vloss, "mean_surrogate_loss": sloss, "rewbuffer": self.rewbuffer,
+                    "lenbuffer": self.lenbuffer, "ep_infos": [ep] if ep else [], "it": it,
+                    "collection_time": collection_time, "learn_time": learn_time, "tot_iter": tot_iter}
+            self.wandb_callback(locs, ppo.learning_rate, mean_std, self.alg.actor_critic.state_dict(),
+                                ppo.optimizer_state_dict(), self.device, 0)
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, path, infos=None):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"model_state_dict": {k: v.cpu() for k, v in self.ppo.state_dict().items()},
+                    "optimizer_state_dict": {k: (v.cpu() if torch.is_tensor(v) else v)
+                                             for k, v in self.ppo.optimizer_state_dict().items()},
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        d = torch.load(path, map_location="cpu", weights_only=True)
+        self.ppo.load_state_dict(d["model_state_dict"])
+        if load_optimizer and "adam_m" in d.get("optimizer_state_dict", {}):
+            self.ppo.load_optimizer_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = d["iter"]
+        return d.get("infos")
+
+    def get_inference_policy(self, device=None):
+        return self.ppo.act_inference
