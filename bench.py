@@ -18,6 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# host threads for the cpu_baseline leg: the GPU box gives a 1-GPU job a 16-CPU share
+CPU_THREADS = max(1, min(16, os.cpu_count() or 1))
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
 
 import torch  # noqa: E402
 
@@ -64,23 +67,29 @@ def time_iterations(runner, steps, warmup, world):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    t_roll = 0.0
-    for _ in range(steps):
-        a = time.perf_counter()
+    for _ in range(steps):                       # timed region: no host synchronisation inside
         runner.rollout()
-        torch.cuda.synchronize()
-        t_roll += time.perf_counter() - a
         runner.ppo.update(ar)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # informative rollout/update split, measured separately with a sync between the phases
+    t_roll = 0.0
+    for _ in range(2):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        runner.rollout()
+        torch.cuda.synchronize()
+        t_roll += (time.perf_counter() - a) / 2
+        runner.ppo.update(ar)
+    torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([el, t_roll], device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el, t_roll = float(t[0]), float(t[1])
-    return el, t_roll
+    return el, t_roll * steps
 
 
 def gemm_roofline(runner, hidden, reps=8):
@@ -133,42 +142,38 @@ def cpu_baseline(num_envs, hidden):
     from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
     from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
     from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
-    cores = os.cpu_count() or 1
+    cores = CPU_THREADS
     torch.set_num_threads(cores)
     cfg = AnymalCFlatCfg()
     cfg.env.num_envs = num_envs
     cm = compile_model(resolve_model("", "anymal_c"))
     env = oracle_lib.OracleEnv(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), seed=1))
     env.call("reset_all")
-    T, A, O = 24, 12, 48
+    T, A, O, TS = 24, 12, 48, 4                     # TS of the 24 rollout steps are actually run
     ac = ppo_torch.ActorCritic(O, O, A, hidden, hidden)
     algo = ppo_torch.PPO(ac)
-    obs_buf = torch.zeros(T, num_envs, O)
+    obs = torch.from_numpy(env.buf["obs"]).clone()
     t0 = time.perf_counter()
     with torch.no_grad():
-        for t in range(T):
-            obs = torch.from_numpy(env.buf["obs"])
-            obs_buf[t] = obs
+        for t in range(TS):
+            obs = torch.from_numpy(env.buf["obs"]).clone()
             act = ac.act(obs)
             ac.evaluate(obs)
             env.step(act.numpy())
-    t_roll = time.perf_counter() - t0
+    t_roll = (time.perf_counter() - t0) * T / TS
     R = T * num_envs // 4
-    flat = obs_buf.reshape(T * num_envs, O)
+    o = obs.repeat((R + num_envs - 1) // num_envs, 1)[:R] + 0.01 * torch.randn(R, O)
+    with torch.no_grad():
+        mu = ac.actor(o)
     t0 = time.perf_counter()
-    for mb in range(4):
-        idx = torch.arange(mb * R, (mb + 1) * R)
-        o = flat[idx]
-        with torch.no_grad():
-            mu = ac.actor(o)
-        algo.step_minibatch(o, o, mu + 0.1, torch.zeros(R, 1), torch.randn(R, 1), torch.randn(R, 1),
-                            torch.zeros(R, 1), mu, torch.ones(R, A))
-    t_epoch = time.perf_counter() - t0
+    algo.step_minibatch(o, o, mu + 0.1, torch.zeros(R, 1), torch.randn(R, 1), torch.randn(R, 1),
+                        torch.zeros(R, 1), mu, torch.ones(R, A))
+    t_mb = time.perf_counter() - t0
     env.close()
-    total = t_roll + 5 * t_epoch
+    total = t_roll + 20 * t_mb
     return {"value": round(T * num_envs / total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 rollout (24 steps x {num_envs} envs, oracle C++/OpenMP env + torch policy) measured {t_roll:.2f}s; "
-                      f"1 of 5 update epochs measured {t_epoch:.2f}s and scaled x5"}
+            "sample": f"{TS} of 24 rollout steps x {num_envs} envs (oracle C++/OpenMP env + torch policy, scaled x{T // TS}: "
+                      f"{t_roll:.2f}s) + 1 of 20 minibatch updates ({t_mb:.2f}s, scaled x20); {cores} threads"}
 
 
 def main():

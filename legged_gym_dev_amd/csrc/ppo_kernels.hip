@@ -19,48 +19,62 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // EPI 2: C += acc via float atomics, reduction split over blockIdx.y   (weight gradient)
 #define BK 32
 
-template <bool RC, int ROWS>
+template <bool RC, int ROWS, bool VEC>
 __device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld, int row0, int red0, int nrows, int nred,
-                                           bool vec_ok, float4 (&regs)[ROWS * BK / 4 / 256]) {
+                                           float4 (&regs)[ROWS * BK / 4 / 256], unsigned &mask) {
     constexpr int NV = ROWS * BK / 4 / 256;
     const int tid = threadIdx.x;
+    const int row_lim = RC ? nrows : nred, col_lim = RC ? nred : nrows;
+    mask = 0u;                          // bit v: regs[v] is in range (applied at stage_store, so that nothing
+                                        // consumes the loaded data -- and waits on it -- before the MFMA block)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        int idx = tid + v * 256;
+        const int idx = tid + v * 256;
         int r, c;                       // r: index along the tile's non-contiguous dim, c: float4 along the contiguous one
         if (RC) { c = idx & (BK / 4 - 1); r = idx / (BK / 4); }
         else { c = idx & (ROWS / 4 - 1); r = idx / (ROWS / 4); }
-        int grow = RC ? row0 + r : red0 + r;        // global row
-        int gcol = RC ? red0 + 4 * c : row0 + 4 * c;
-        int row_lim = RC ? nrows : nred, col_lim = RC ? nred : nrows;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow < row_lim) {
-            const float *p = src + (size_t)grow * ld + gcol;
-            if (vec_ok && gcol + 3 < col_lim) val = *reinterpret_cast<const float4 *>(p);
-            else {
-                if (gcol < col_lim) val.x = p[0];
-                if (gcol + 1 < col_lim) val.y = p[1];
-                if (gcol + 2 < col_lim) val.z = p[2];
-                if (gcol + 3 < col_lim) val.w = p[3];
+        const int grow = RC ? row0 + r : red0 + r;        // global row
+        const int gcol = RC ? red0 + 4 * c : row0 + 4 * c;
+        if (VEC) {
+            // branch-free: every lane loads 16 B from a clamped (always valid) address and zeroes it by
+            // select when out of range -- a guarded load makes hipcc wait vmcnt(0) per element.
+            // VEC implies col_lim % 4 == 0, so a float4 is entirely inside or entirely outside.
+            const int rc_ = min(grow, row_lim - 1), cc_ = min(gcol, col_lim - 4);
+            regs[v] = *reinterpret_cast<const float4 *>(src + (size_t)rc_ * ld + cc_);
+            mask |= (grow < row_lim && gcol < col_lim) ? (1u << v) : 0u;
+        } else {
+            const int rc_ = min(grow, row_lim - 1);
+            const float *p = src + (size_t)rc_ * ld;
+            const bool rin = grow < row_lim;
+            float e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cc_ = min(gcol + q, col_lim - 1);
+                const float x = p[cc_];
+                e[q] = (rin && gcol + q < col_lim) ? x : 0.f;
             }
+            regs[v] = make_float4(e[0], e[1], e[2], e[3]);
+            mask |= 1u << v;
         }
-        regs[v] = val;
     }
 }
 template <bool RC, int ROWS>
-__device__ __forceinline__ void stage_store(float *__restrict__ lds, const float4 (&regs)[ROWS * BK / 4 / 256]) {
+__device__ __forceinline__ void stage_store(float *__restrict__ lds, const float4 (&regs_in)[ROWS * BK / 4 / 256], unsigned mask) {
     constexpr int NV = ROWS * BK / 4 / 256;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         int idx = tid + v * 256;
+        const bool in = (mask >> v) & 1u;
+        float4 regs[1];
+        regs[0] = make_float4(in ? regs_in[v].x : 0.f, in ? regs_in[v].y : 0.f, in ? regs_in[v].z : 0.f, in ? regs_in[v].w : 0.f);
         if (RC) {                       // lds[r][BK+1]
             int c = idx & (BK / 4 - 1), r = idx / (BK / 4);
             float *d = lds + r * (BK + 1) + 4 * c;
-            d[0] = regs[v].x; d[1] = regs[v].y; d[2] = regs[v].z; d[3] = regs[v].w;
+            d[0] = regs[0].x; d[1] = regs[0].y; d[2] = regs[0].z; d[3] = regs[0].w;
         } else {                        // lds[k][ROWS+4]
             int c = idx & (ROWS / 4 - 1), r = idx / (ROWS / 4);
-            *reinterpret_cast<float4 *>(lds + r * (ROWS + 4) + 4 * c) = regs[v];
+            *reinterpret_cast<float4 *>(lds + r * (ROWS + 4) + 4 * c) = regs[0];
         }
     }
 }
@@ -70,6 +84,68 @@ __device__ __forceinline__ float frag(const float *__restrict__ lds, int row, in
 }
 template <bool RC, int ROWS>
 constexpr int tile_floats() { return RC ? ROWS * (BK + 1) : BK * (ROWS + 4); }
+
+template <bool A_RC, bool B_RC, int TM, int TN, bool VEC>
+__device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
+                                              int M, int N, int k_begin, int k_end, float *__restrict__ lds, int wm, int wn, int li, int lk,
+                                              f32x16 (&acc)[TM][TN]) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
+    float4 ra[BM * BK / 4 / 256], rb[BN * BK / 4 / 256];
+    unsigned ma, mb_;
+    stage_load<A_RC, BM, VEC>(A, lda, m0, k_begin, M, k_end, ra, ma);
+    stage_load<B_RC, BN, VEC>(B, ldb, n0, k_begin, N, k_end, rb, mb_);
+    stage_store<A_RC, BM>(lds, ra, ma);
+    stage_store<B_RC, BN>(lds + AF, rb, mb_);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = k0 + BK < k_end;
+        if (more) {
+            stage_load<A_RC, BM, VEC>(A, lda, m0, k0 + BK, M, k_end, ra, ma);
+            stage_load<B_RC, BN, VEC>(B, ldb, n0, k0 + BK, N, k_end, rb, mb_);
+        }
+        const float *as = lds + cur * (AF + BF), *bs = as + AF;
+        // fragments are fetched one group (GS k-steps) ahead of the MFMAs that consume them, so the
+        // LDS latency is paid once per k-tile instead of once per k-step
+        constexpr int GS = 4, NG = BK / 2 / GS;
+        float av[2][GS][TM], bv[2][GS][TN];
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[0][s][a] = frag<A_RC, BM>(as, wm + 32 * a + li, 2 * s + lk);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[0][s][b] = frag<B_RC, BN>(bs, wn + 32 * b + li, 2 * s + lk);
+        }
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int s = 0; s < GS; ++s) {
+                    const int ks = 2 * ((gq + 1) * GS + s) + lk;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) av[(gq + 1) & 1][s][a] = frag<A_RC, BM>(as, wm + 32 * a + li, ks);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) bv[(gq + 1) & 1][s][b] = frag<B_RC, BN>(bs, wn + 32 * b + li, ks);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < GS; ++s)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gq & 1][s][a], bv[gq & 1][s][b], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            stage_store<A_RC, BM>(lds + (cur ^ 1) * (AF + BF), ra, ma);
+            stage_store<B_RC, BN>(lds + (cur ^ 1) * (AF + BF) + AF, rb, mb_);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+}
 
 template <bool A_RC, bool B_RC, int EPI, int TM, int TN>
 __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
@@ -91,8 +167,9 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     const float *__restrict__ A = g.A[z];
     const float *__restrict__ B = g.B[z];
     const int lda = g.lda[z], ldb = g.ldb[z], ldc = g.ldc[z];
-    const bool a_vec = (lda & 3) == 0 && ((uintptr_t)A & 15) == 0;
-    const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0;
+    // 16-byte path: aligned rows and a contiguous-dimension limit that no float4 straddles
+    const bool a_vec = (lda & 3) == 0 && ((uintptr_t)A & 15) == 0 && (((A_RC ? k_end : M) & 3) == 0) && (A_RC ? k_end : M) >= 4;
+    const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (((B_RC ? k_end : N) & 3) == 0) && (B_RC ? k_end : N) >= 4;
 
     constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
     __shared__ float lds[2 * (AF + BF)];
@@ -109,43 +186,54 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    float4 ra[BM * BK / 4 / 256], rb[BN * BK / 4 / 256];
-    stage_load<A_RC, BM>(A, lda, m0, k_begin, M, k_end, a_vec, ra);
-    stage_load<B_RC, BN>(B, ldb, n0, k_begin, N, k_end, b_vec, rb);
-    stage_store<A_RC, BM>(lds, ra);
-    stage_store<B_RC, BN>(lds + AF, rb);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        const bool more = k0 + BK < k_end;
-        if (more) {
-            stage_load<A_RC, BM>(A, lda, m0, k0 + BK, M, k_end, a_vec, ra);
-            stage_load<B_RC, BN>(B, ldb, n0, k0 + BK, N, k_end, b_vec, rb);
-        }
-        const float *as = lds + cur * (AF + BF), *bs = as + AF;
-#pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) av[a] = frag<A_RC, BM>(as, wm + 32 * a + li, 2 * s + lk);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bv[b] = frag<B_RC, BN>(bs, wn + 32 * b + li, 2 * s + lk);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
-        if (more) {
-            stage_store<A_RC, BM>(lds + (cur ^ 1) * (AF + BF), ra);
-            stage_store<B_RC, BN>(lds + (cur ^ 1) * (AF + BF) + AF, rb);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
+    if (a_vec && b_vec) gemm_mainloop<A_RC, B_RC, TM, TN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
+    else gemm_mainloop<A_RC, B_RC, TM, TN, false>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
 
     // ---- epilogue.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *__restrict__ C = g.C[z];
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= N);     // workgroup-uniform
+    const int elu = g.elu;
+    if (interior) {
+        // unguarded path: loads of the epilogue operand are issued as one batch (no per-element branch,
+        // which would serialise them behind s_waitcnt vmcnt(0)), then compute + store
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int n = n0 + wn + 32 * b + li;
+            float csum = 0.f;
+            const float bias = (EPI == 0 && g.bias[z]) ? g.bias[z][n] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int mb = m0 + wm + 32 * a + 4 * lk;
+                float aux[16];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        aux[r] = g.aux[z][(size_t)(mb + (r & 3) + 8 * (r >> 2)) * g.ldaux[z] + n];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *cp = &C[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * ldc + n];
+                    float v = acc[a][b][r];
+                    if (EPI == 0) {
+                        v += bias;
+                        if (elu) v = v > 0.f ? v : __expf(v) - 1.0f;
+                        *cp = v;
+                    } else if (EPI == 1) {
+                        v *= aux[r] > 0.f ? 1.0f : aux[r] + 1.0f;
+                        *cp = v;
+                        csum += v;
+                    } else {
+                        atomicAdd(cp, v);
+                    }
+                }
+            }
+            if (EPI == 1 && g.colsum[z]) {
+                csum += __shfl_xor(csum, 32);
+                if (lk == 0) atomicAdd(&g.colsum[z][n], csum);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn + 32 * b + li;
@@ -160,7 +248,7 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
                     float v = acc[a][b][r];
                     if (EPI == 0) {
                         v += bias;
-                        if (g.elu) v = v > 0.f ? v : expm1f(v);
+                        if (elu) v = v > 0.f ? v : __expf(v) - 1.0f;
                         C[(size_t)m * ldc + n] = v;
                     } else if (EPI == 1) {
                         const float act = g.aux[z][(size_t)m * g.ldaux[z] + n];
@@ -337,32 +425,40 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const float *std = P.params + P.off_std;
     const float invR = 1.0f / (float)R;
-    // per-thread partials: [0..A) dstd, [A..2A) dbias_actor_head, 2A dbias_critic_head, then kl, vloss, sloss
-    float part[2 * LG_PPO_MAX_A + 4];
-    for (int k = 0; k < 2 * A + 4; ++k) part[k] = 0.f;
+    // per-thread partials at fixed slots: [0..MA) dstd, [MA..2MA) dbias_actor_head, 2MA dbias_critic_head, kl, vloss, sloss
+    constexpr int MA = LG_PPO_MAX_A;
+    float part[2 * MA + 4];
+#pragma unroll
+    for (int k = 0; k < 2 * MA + 4; ++k) part[k] = 0.f;
     if (r < R) {
-        const float v_old = P.mb_scalars[(size_t)r * 4 + 0], ret = P.mb_scalars[(size_t)r * 4 + 1];
-        const float adv = P.mb_scalars[(size_t)r * 4 + 2], lp_old = P.mb_scalars[(size_t)r * 4 + 3];
-        float lp = 0.f, kl = 0.f;
-        for (int a = 0; a < A; ++a) {
-            const float s = std[a], so = P.st_sigma[a];
-            const float m = mu_new[(size_t)r * A + a], mo = P.mb_mu[(size_t)r * A + a];
-            const float d = P.mb_actions[(size_t)r * A + a] - m;
-            lp += -(d * d) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
-            kl += logf(s / so + 1.e-5f) + (so * so + (mo - m) * (mo - m)) / (2.0f * s * s) - 0.5f;
+        const float4 sc = reinterpret_cast<const float4 *>(P.mb_scalars)[r];
+        const float v_old = sc.x, ret = sc.y, adv = sc.z, lp_old = sc.w;
+        float lp = 0.f, kl = 0.f, dd[MA];
+#pragma unroll
+        for (int a = 0; a < MA; ++a) {
+            dd[a] = 0.f;
+            if (a < A) {
+                const float s = std[a], so = P.st_sigma[a];
+                const float m = mu_new[(size_t)r * A + a], mo = P.mb_mu[(size_t)r * A + a];
+                const float d = P.mb_actions[(size_t)r * A + a] - m;
+                dd[a] = d;
+                lp += -(d * d) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+                kl += logf(s / so + 1.e-5f) + (so * so + (mo - m) * (mo - m)) / (2.0f * s * s) - 0.5f;
+            }
         }
         const float ratio = expf(lp - lp_old);
         const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
         const float s1 = -adv * ratio, s2 = -adv * rc;
         const float dl_dlp = (s1 >= s2 ? -adv : 0.0f) * ratio * invR;        // torch.max ties: see DESIGN.md
-        for (int a = 0; a < A; ++a) {
-            const float s = std[a];
-            const float d = P.mb_actions[(size_t)r * A + a] - mu_new[(size_t)r * A + a];
-            const float g = dl_dlp * d / (s * s);
-            dmu[(size_t)r * A + a] = g;
-            part[A + a] = g;
-            part[a] = dl_dlp * (d * d / (s * s * s) - 1.0f / s) - P.entropy_coef * invR / s;
-        }
+#pragma unroll
+        for (int a = 0; a < MA; ++a)
+            if (a < A) {
+                const float s = std[a], d = dd[a];
+                const float g = dl_dlp * d / (s * s);
+                dmu[(size_t)r * A + a] = g;
+                part[MA + a] = g;
+                part[a] = dl_dlp * (d * d / (s * s * s) - 1.0f / s) - P.entropy_coef * invR / s;
+            }
         const float v = v_new[r];
         float lv, dv;
         if (P.clipped_value) {
@@ -380,30 +476,34 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
         }
         dv *= P.value_coef * invR;
         dval[r] = dv;
-        part[2 * A] = dv;
-        part[2 * A + 1] = kl;
-        part[2 * A + 2] = lv;
-        part[2 * A + 3] = fmaxf(s1, s2);
+        part[2 * MA] = dv;
+        part[2 * MA + 1] = kl;
+        part[2 * MA + 2] = lv;
+        part[2 * MA + 3] = fmaxf(s1, s2);
     }
-    // block reduction of the partial vector through LDS
-    __shared__ float red[256];
-    for (int k = 0; k < 2 * A + 4; ++k) {
-        red[threadIdx.x] = part[k];
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-            __syncthreads();
+    // wave64 butterfly per partial, one LDS atomic per wave, one global atomic per block and partial
+    __shared__ float red[2 * MA + 4];
+    if (threadIdx.x < 2 * MA + 4) red[threadIdx.x] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2 * MA + 4; ++k) {
+        if (k >= 2 * MA || (k % MA) < A) {
+            float v = part[k];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], v);
         }
-        if (threadIdx.x == 0) {
-            float v = red[0];
-            if (k < A) atomicAdd(&P.grads[P.off_std + k], v);
-            else if (k < 2 * A) atomicAdd(&P.grads[P.off_bias_actor_head + (k - A)], v);
-            else if (k == 2 * A) atomicAdd(&P.grads[P.off_bias_critic_head], v);
-            else if (k == 2 * A + 1) atomicAdd(&P.grads[P.num_params], v);          // KL sum rides in the grad buffer tail
-            else if (k == 2 * A + 2) atomicAdd(&P.loss_acc[0], v);
-            else atomicAdd(&P.loss_acc[1], v);
-        }
-        __syncthreads();
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < 2 * MA + 4 && (k >= 2 * MA || (k % MA) < A)) {
+        const float v = red[k];
+        if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
+        else if (k < 2 * MA) atomicAdd(&P.grads[P.off_bias_actor_head + (k - MA)], v);
+        else if (k == 2 * MA) atomicAdd(&P.grads[P.off_bias_critic_head], v);
+        else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);             // KL sum rides in the grad buffer tail
+        else if (k == 2 * MA + 2) atomicAdd(&P.loss_acc[0], v);
+        else atomicAdd(&P.loss_acc[1], v);
     }
 }
 

@@ -31,6 +31,7 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  -- first, so that liblegged_hip binds to the HIP runtime instance torch uses
         if not os.path.isfile(SO_PATH):
             raise LeggedHipError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
