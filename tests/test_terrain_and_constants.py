@@ -1,0 +1,62 @@
+"""Host-side setup pinned against the reference: this repo's Terrain class reproduces the height field
+and tile origins the reference's Terrain class built (same generators, same numpy seed), and
+draw_env_constants reproduces friction / base-mass / origins / terrain levels draw for draw."""
+import numpy as np
+import pytest
+import torch
+
+from tests import harness
+
+SEEDS = {"anymal_c_flat": 11, "anymal_c_rough": 12, "cassie": 13}
+
+
+@pytest.mark.parametrize("name", ["anymal_c_rough", "cassie"])
+def test_terrain_matches_reference(name):
+    from legged_gym_dev_amd.utils.terrain import Terrain
+    z, meta = harness.load_fixture(name)
+    cfg = harness.make_cfg(name)
+    np.random.seed(SEEDS[name])
+    t = Terrain(cfg.terrain, cfg.env.num_envs)
+    np.testing.assert_array_equal(t.heightsamples, z["const_height_samples"])
+    np.testing.assert_allclose(t.env_origins, z["const_terrain_origins"], rtol=0, atol=1e-6)
+    assert (t.tot_rows, t.tot_cols) == z["const_height_samples"].shape
+    assert t.vertices.shape[0] == t.tot_rows * t.tot_cols and t.triangles.shape[1] == 3
+
+
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
+def test_env_constants_match_reference_draws(name):
+    from legged_gym_dev_amd.envs.base.legged_robot import draw_env_constants
+    from legged_gym_dev_amd.model.robot_model import resolve_model
+    from legged_gym_dev_amd.utils.terrain import Terrain
+    z, meta = harness.load_fixture(name)
+    cfg = harness.make_cfg(name)
+    torch.manual_seed(SEEDS[name])
+    np.random.seed(SEEDS[name])
+    terrain = Terrain(cfg.terrain, cfg.env.num_envs) if cfg.terrain.mesh_type in ("heightfield", "trimesh") else None
+    model = resolve_model("", meta["robot"])
+    c = draw_env_constants(cfg, cfg.env.num_envs, float(model["bodies"][0]["mass"]), terrain)
+    np.testing.assert_allclose(c["env_origins"].numpy(), z["const_env_origins_init"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(c["friction"].numpy(), z["const_friction_coeffs"])
+    if cfg.domain_rand.randomize_base_mass:
+        np.testing.assert_allclose(c["base_mass"], z["const_base_mass"], rtol=1e-12)
+    if terrain is not None:
+        np.testing.assert_array_equal(c["terrain_levels"].numpy(), z["const_terrain_levels_init"])
+        np.testing.assert_array_equal(c["terrain_types"].numpy(), z["const_terrain_types"])
+
+
+def test_sharded_constants_are_slices_of_the_global_draw():
+    """rank r of G owns envs [r N/G, (r+1) N/G): per-env constants and terrain types use GLOBAL ids."""
+    from legged_gym_dev_amd.envs.base.legged_robot import draw_env_constants
+    from legged_gym_dev_amd.utils.terrain import Terrain
+    cfg = harness.make_cfg("anymal_c_rough")
+    np.random.seed(3)
+    terrain = Terrain(cfg.terrain, 128)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        np.random.seed(4)
+        outs.append(draw_env_constants(cfg, 128, 26.0, terrain))
+    for k in ("env_origins", "friction", "terrain_levels", "terrain_types"):
+        assert torch.equal(outs[0][k], outs[1][k])
+    types = outs[0]["terrain_types"]
+    assert types.min() == 0 and types.max() == cfg.terrain.num_cols - 1 and (types[1:] >= types[:-1]).all()
