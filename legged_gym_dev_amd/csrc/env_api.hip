@@ -9,7 +9,7 @@ static thread_local std::string g_err;
 void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
-extern "C" void lgk_torques(const DevParams *P, int n, hipStream_t s);
+extern "C" void lgk_torques(const DevParams *P, int n, int lstm, hipStream_t s);
 extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s);
 extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
@@ -178,7 +178,7 @@ int lg_set_actions(lg_ctx *c, const float *actions) {
     return chk_launch();
 }
 int lg_compute_torques(lg_ctx *c) {
-    lgk_torques(c->d, c->h.cfg.num_envs * c->h.cfg.num_actions, c->stream);
+    lgk_torques(c->d, c->h.cfg.num_envs * c->h.cfg.num_actions, c->h.cfg.use_actuator_net, c->stream);
     return chk_launch();
 }
 int lg_simulate(lg_ctx *c) {

@@ -99,10 +99,69 @@ __global__ void __launch_bounds__(256) k_torques(const DevParams *__restrict__ P
     P->buf.torques[ij] = tau;
 }
 
+// Actuator net, wide form: 8 lanes per (env, joint) row, lane k owns hidden unit k of both LSTM
+// layers (its 4 gate rows: 112 weights + lin_w[k] resident in VGPRs, staged through LDS once per
+// block).  The 8 hidden values of a row are exchanged with width-8 shuffles; the state (2, N*A, 8)
+// is read/written 4 B per lane, fully coalesced.  6 waves per SIMD at 4096 envs instead of <1.
+__device__ __forceinline__ float fsigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+__global__ void __launch_bounds__(256) k_torques_lstm8(const DevParams *__restrict__ P) {
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions, n = c.num_envs * A;
+    __shared__ float w[LG_LSTM_NW];
+    for (int i = threadIdx.x; i < LG_LSTM_NW; i += 256) w[i] = c.lstm_w[i];
+    __syncthreads();
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    int row = gid >> 3;
+    const int k = gid & 7;
+    const bool live = row < n;
+    if (!live) row = n - 1;
+    const float *wih0 = w + 3, *whh0 = wih0 + 64, *bih0 = whh0 + 256, *bhh0 = bih0 + 32;
+    const float *wih1 = bhh0 + 32, *whh1 = wih1 + 256, *bih1 = whh1 + 256, *bhh1 = bih1 + 32;
+    const float *lw = bhh1 + 32, *lb = lw + 8;
+    const int j = row % A;
+    const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[row];
+    const float x0 = (P->buf.actions[row] * c.action_scale + c.default_dof_pos[j] - st.x) * w[0], x1 = st.y * w[1];
+    const size_t ls = (size_t)n * 8, idx = (size_t)row * 8 + k;
+    float h0 = P->buf.lstm_h[idx], c0 = P->buf.lstm_c[idx], h1 = P->buf.lstm_h[ls + idx], c1 = P->buf.lstm_c[ls + idx];
+    float g0[4], g1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r = g * 8 + k;
+        g0[g] = bih0[r] + bhh0[r] + wih0[r * 2] * x0 + wih0[r * 2 + 1] * x1;
+        g1[g] = bih1[r] + bhh1[r];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float hq = __shfl(h0, q, 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g0[g] += whh0[(g * 8 + k) * 8 + q] * hq;
+    }
+    c0 = fsigm(g0[1]) * c0 + fsigm(g0[0]) * ftanh(g0[2]);
+    h0 = fsigm(g0[3]) * ftanh(c0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float xq = __shfl(h0, q, 8), hq = __shfl(h1, q, 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g1[g] += wih1[(g * 8 + k) * 8 + q] * xq + whh1[(g * 8 + k) * 8 + q] * hq;
+    }
+    c1 = fsigm(g1[1]) * c1 + fsigm(g1[0]) * ftanh(g1[2]);
+    h1 = fsigm(g1[3]) * ftanh(c1);
+    float y = lw[k] * h1;
+    y += __shfl_xor(y, 1, 8);
+    y += __shfl_xor(y, 2, 8);
+    y += __shfl_xor(y, 4, 8);
+    if (live) {
+        P->buf.lstm_h[idx] = h0; P->buf.lstm_c[idx] = c0; P->buf.lstm_h[ls + idx] = h1; P->buf.lstm_c[ls + idx] = c1;
+        if (k == 0) P->buf.torques[row] = w[2] * (y + lb[0]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gym.simulate replacement (LR:92-96): one wave = 64/L environments, lane = (env, leg).
 template <int L, int J>
-__global__ void __launch_bounds__(64) k_physics(const DevParams *__restrict__ P) {
+__global__ void __launch_bounds__(64, 1) k_physics(const DevParams *__restrict__ P) {
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
     const int gl = blockIdx.x * 64 + threadIdx.x;
@@ -128,11 +187,13 @@ __global__ void __launch_bounds__(64) k_physics(const DevParams *__restrict__ P)
             const int dyn = m.body_dyn[b];
             if ((dyn < 0 ? 0 : dyn / J) == leg) { cf[3 * b] = 0.f; cf[3 * b + 1] = 0.f; cf[3 * b + 2] = 0.f; }
         }
+    __shared__ float s_ct[(LG_MAX_LEG_SLOTS + 1) * LG_CT_NF * 64];
+    __shared__ float s_lk[J * LG_LK_NF * 64];
     const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
     for (int s = 0; s < ns; ++s) {
         V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-        physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase);
+        physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk);
         V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
         if (live) {
 #pragma unroll
@@ -511,8 +572,9 @@ extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipSt
     int blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_set_actions, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, P, a);
 }
-extern "C" void lgk_torques(const DevParams *P, int n, hipStream_t s) {
-    hipLaunchKernelGGL(k_torques, dim3((n + 255) / 256), dim3(256), 0, s, P);
+extern "C" void lgk_torques(const DevParams *P, int n, int lstm, hipStream_t s) {
+    if (lstm) hipLaunchKernelGGL(k_torques_lstm8, dim3((n * 8 + 255) / 256), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(k_torques, dim3((n + 255) / 256), dim3(256), 0, s, P);
 }
 extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s) {
     const int blocks = (N * L + 63) / 64;

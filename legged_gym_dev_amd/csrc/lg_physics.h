@@ -55,7 +55,7 @@ __device__ __forceinline__ M6 rigid_inertia(float m, V3 c, const M3 &Ic) {
     return I;
 }
 __device__ __forceinline__ bool spd_inverse6(const M6 &A, M6 &Ainv) {
-    float Lm[6][6];
+    float Lm[6][6], Li[6];            // Li = 1 / diag(L): v_rsq instead of IEEE divisions
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -68,8 +68,8 @@ __device__ __forceinline__ bool spd_inverse6(const M6 &A, M6 &Ainv) {
             float s = A.m[i][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
-            if (i == j) { ok = ok && (s > 0.0f); Lm[i][i] = sqrtf(fmaxf(s, 1e-30f)); }
-            else Lm[i][j] = s / Lm[j][j];
+            if (i == j) { ok = ok && (s > 0.0f); Li[i] = rsqrtf(fmaxf(s, 1e-30f)); Lm[i][i] = s * Li[i]; }
+            else Lm[i][j] = s * Li[j];
         }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -79,14 +79,14 @@ __device__ __forceinline__ bool spd_inverse6(const M6 &A, M6 &Ainv) {
             float s = (i == c) ? 1.0f : 0.0f;
 #pragma unroll
             for (int k = 0; k < i; ++k) s -= Lm[i][k] * y[k];
-            y[i] = s / Lm[i][i];
+            y[i] = s * Li[i];
         }
 #pragma unroll
         for (int i = 5; i >= 0; --i) {
             float s = y[i];
 #pragma unroll
             for (int k = i + 1; k < 6; ++k) s -= Lm[k][i] * x[k];
-            x[i] = s / Lm[i][i];
+            x[i] = s * Li[i];
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) Ainv.m[i][c] = x[i];
@@ -94,8 +94,7 @@ __device__ __forceinline__ bool spd_inverse6(const M6 &A, M6 &Ainv) {
     return ok;
 }
 __device__ __forceinline__ M3 rodrigues(V3 a, float th) {
-    float s, c;
-    sincosf(th, &s, &c);
+    const float s = __sinf(th), c = __cosf(th);      // |th| is a joint angle: the fast forms are accurate to ~1e-6
     float t = 1.0f - c;
     M3 R = {{{c + t * a.x * a.x, t * a.x * a.y - s * a.z, t * a.x * a.z + s * a.y},
              {t * a.x * a.y + s * a.z, c + t * a.y * a.y, t * a.y * a.z - s * a.x},
@@ -136,22 +135,18 @@ __device__ __forceinline__ Ground ground_at(const DevParams *P, float x, float y
     float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
     float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hf_hscale;
     float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hf_hscale;
-    float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    float inv = rsqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     return {h, {-dhdx * inv, -dhdy * inv, inv}};
 }
 
 
 
-struct Contact {           // one sphere slot of this lane
-    V3 P, n;
-    float W00, W10, W20, W11, W21, W22;
-    float vtarget, relax, ln, l1, l2;
-    bool active;
-};
+#define LG_CT_NF 17      // floats per contact-slot record
+#define LG_LK_NF 24      // floats per link record: R 9, p 3, vel 6, c 6
 __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
     V3 ref = fabsf(n.x) < 0.9f ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f};
     V3 t = cross(n, ref);
-    t1 = (1.0f / sqrtf(dot(t, t))) * t;
+    t1 = rsqrtf(dot(t, t)) * t;
     t2 = cross(n, t1);
 }
 
@@ -161,7 +156,7 @@ __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
 template <int L, int J>
 __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
                                              float *qd, const float *tau, float friction, float dmass,
-                                             V3 *fslot, V3 &fbase) {
+                                             V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt) {
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
     const int d0 = leg * J;
@@ -171,10 +166,13 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
     const V3 gb = mulT(Rb, V3{c.gravity[0], c.gravity[1], c.gravity[2]});
     const Sv vel0 = {wb, vb};
 
-    M3 Rl[J];
-    V3 pl[J];
-    Sv S[J], vel[J], cb[J], U[J];
-    float D[J], u[J];
+    // Per-link tile staged in LDS (field-major, one column per lane): rotation, origin, velocity and
+    // velocity-product term of every link of this leg.  Only S, U, 1/D, u stay in VGPRs across phases.
+    const int lane = threadIdx.x & 63;
+#define LK(j, f) lkt[((j) * LG_LK_NF + (f)) * 64 + lane]
+    Sv S[J], U[J];
+    float iD[J], u[J];
+    const float inv_dt = __frcp_rn(dt);
     {   // outward kinematics
         M3 Rpar = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
         V3 ppar = {0.f, 0.f, 0.f};
@@ -184,14 +182,21 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
             const int d = d0 + j;
             M3 Rj = mul(Rpar, load3(m.R_pj[d]));
             V3 ax = ld3(m.axis[d]);
-            pl[j] = ppar + mul(Rpar, ld3(m.p_pj[d]));
+            V3 pj = ppar + mul(Rpar, ld3(m.p_pj[d]));
             V3 axb = mul(Rj, ax);
-            Rl[j] = mul(Rj, rodrigues(ax, q[j]));
-            S[j] = {axb, cross(pl[j], axb)};
+            M3 Rlj = mul(Rj, rodrigues(ax, q[j]));
+            S[j] = {axb, cross(pj, axb)};
             Sv vj = qd[j] * S[j];
-            vel[j] = vpar + vj;
-            cb[j] = crm(vel[j], vj);
-            Rpar = Rl[j]; ppar = pl[j]; vpar = vel[j];
+            Sv velj = vpar + vj;
+            Sv cbj = crm(velj, vj);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) LK(j, e) = Rlj.m[e / 3][e % 3];
+            LK(j, 9) = pj.x; LK(j, 10) = pj.y; LK(j, 11) = pj.z;
+            LK(j, 12) = velj.w.x; LK(j, 13) = velj.w.y; LK(j, 14) = velj.w.z;
+            LK(j, 15) = velj.v.x; LK(j, 16) = velj.v.y; LK(j, 17) = velj.v.z;
+            LK(j, 18) = cbj.w.x; LK(j, 19) = cbj.w.y; LK(j, 20) = cbj.w.z;
+            LK(j, 21) = cbj.v.x; LK(j, 22) = cbj.v.y; LK(j, 23) = cbj.v.z;
+            Rpar = Rlj; ppar = pj; vpar = velj;
         }
     }
     // inward pass along the chain
@@ -204,24 +209,31 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
 #pragma unroll
     for (int j = J - 1; j >= 0; --j) {
         const int d = d0 + j;
-        M3 Ic = mulBT(mul(Rl[j], load3(m.inertia[d + 1])), Rl[j]);
-        M6 IA = rigid_inertia(m.mass[d + 1], pl[j] + mul(Rl[j], ld3(m.com[d + 1])), Ic);
-        Sv pA = crf(vel[j], mul6(IA, vel[j]));
+        M3 Rlj;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rlj.m[e / 3][e % 3] = LK(j, e);
+        const V3 pj = {LK(j, 9), LK(j, 10), LK(j, 11)};
+        const Sv velj = {{LK(j, 12), LK(j, 13), LK(j, 14)}, {LK(j, 15), LK(j, 16), LK(j, 17)}};
+        const Sv cbj = {{LK(j, 18), LK(j, 19), LK(j, 20)}, {LK(j, 21), LK(j, 22), LK(j, 23)}};
+        M3 Ic = mulBT(mul(Rlj, load3(m.inertia[d + 1])), Rlj);
+        M6 IA = rigid_inertia(m.mass[d + 1], pj + mul(Rlj, ld3(m.com[d + 1])), Ic);
+        Sv pA = crf(velj, mul6(IA, velj));
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b) IA.m[a][b] += Ia_run.m[a][b];
         pA = pA + pa_run;
         U[j] = mul6(IA, S[j]);
-        D[j] = sdot(S[j], U[j]);
+        const float Dj = sdot(S[j], U[j]);
         u[j] = (tau[j] - m.joint_damping[d] * qd[j]) - sdot(S[j], pA);
         float Uv[6] = {U[j].w.x, U[j].w.y, U[j].w.z, U[j].v.x, U[j].v.y, U[j].v.z};
-        float invD = 1.0f / D[j];
+        const float invD = __frcp_rn(Dj);
+        iD[j] = invD;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b) Ia_run.m[a][b] = IA.m[a][b] - Uv[a] * Uv[b] * invD;
-        pa_run = pA + mul6(Ia_run, cb[j]) + (u[j] * invD) * U[j];
+        pa_run = pA + mul6(Ia_run, cbj) + (u[j] * invD) * U[j];
     }
     // floating base: own inertia (every lane redundantly) + butterfly sum of the L leg contributions
     M6 I0;
@@ -250,42 +262,42 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
         Sv apar = a0;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            Sv ap = apar + cb[j];
-            float qdd = (u[j] - sdot(U[j], ap)) / D[j];
+            const Sv velj = {{LK(j, 12), LK(j, 13), LK(j, 14)}, {LK(j, 15), LK(j, 16), LK(j, 17)}};
+            const Sv cbj = {{LK(j, 18), LK(j, 19), LK(j, 20)}, {LK(j, 21), LK(j, 22), LK(j, 23)}};
+            Sv ap = apar + cbj;
+            float qdd = (u[j] - sdot(U[j], ap)) * iD[j];
             Sv acc = ap + qdd * S[j];
-            velf[j] = vel[j] + dt * (acc + grav);
+            velf[j] = velj + dt * (acc + grav);
             qdf[j] = qd[j] + dt * qdd;
             apar = acc;
         }
     }
 
-    // ---- contact detection + W per slot
+    // ---- contact detection + W per slot.  Slot records live in this wave's LDS region (one column
+    // per lane, field-major: conflict-free) so the slot loops stay rolled and the VGPR file is left
+    // to the articulated-body quantities.
     const float mu = 0.5f * (friction + c.ground_friction);
-    Contact ct[LG_MAX_LEG_SLOTS + 1];
-    int n_leg_active = 0;
     const int nslots = P->n_leg_slots;
-#pragma unroll
-    for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) {
-        Contact &C = ct[s];
-        C.active = false;
-        C.ln = C.l1 = C.l2 = 0.f;
-        C.relax = 0.f;
-        const bool is_base = (s == LG_MAX_LEG_SLOTS);
-        bool exists = is_base ? (leg < P->n_base_spheres) : (s < nslots);
+#define CF(si, f) cst[((si) * LG_CT_NF + (f)) * 64 + lane]
+    unsigned amask = 0u;                       // bit si: slot si of this lane is in contact
+    for (int s = 0; s <= nslots; ++s) {
+        const bool is_base = (s == nslots);
+        const int si = is_base ? LG_MAX_LEG_SLOTS : s;
+        const bool exists = is_base ? (leg < P->n_base_spheres) : true;
         int jl = 0;
-        V3 cbk = {0.f, 0.f, 0.f};
-        float rad = 0.f;
+        V3 cbk = {0.f, 0.f, 0.f}, Pc = {0.f, 0.f, 0.f}, nb = {0.f, 0.f, 1.f};
+        float rad = 0.f, vtarget = 0.f;
+        bool active = false;
         if (exists) {
             if (is_base) {
                 cbk = ld3(P->base_center[leg]);
                 rad = P->base_radius[leg];
             } else {
                 jl = P->slot_link[s];
-                M3 Rk = Rl[0];
-                V3 pk = pl[0];
+                M3 Rk;
 #pragma unroll
-                for (int k = 1; k < J; ++k)
-                    if (jl == k) { Rk = Rl[k]; pk = pl[k]; }
+                for (int e = 0; e < 9; ++e) Rk.m[e / 3][e % 3] = LK(jl, e);
+                const V3 pk = {LK(jl, 9), LK(jl, 10), LK(jl, 11)};
                 cbk = pk + mul(Rk, ld3(P->slot_center[s][leg]));
                 rad = P->slot_radius[s][leg];
             }
@@ -293,28 +305,30 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
             Ground g = ground_at(P, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
             if (gap < c.contact_offset) {
-                C.active = true;
-                C.n = mulT(Rb, g.n);
-                C.P = cbk - rad * C.n;
-                C.vtarget = gap >= 0.0f ? -gap / dt : fminf(-gap * c.contact_erp / dt, c.max_depenetration_velocity);
+                active = true;
+                nb = mulT(Rb, g.n);
+                Pc = cbk - rad * nb;
+                vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
             }
         }
-        if (!__any(C.active)) continue;                  // wave-uniform skip
-        if (C.active && !is_base) n_leg_active++;
+        CF(si, 16) = active ? 1.0f : 0.0f;
+        CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
+        if (!__any(active)) continue;                    // wave-uniform skip
+        if (active) amask |= 1u << si;
         V3 t1, t2;
-        tangents(C.active ? C.n : V3{0.f, 0.f, 1.f}, t1, t2);
-        V3 dirs[3] = {C.active ? C.n : V3{0.f, 0.f, 1.f}, t1, t2};
+        tangents(nb, t1, t2);
+        V3 dirs[3] = {nb, t1, t2};
         float Wc[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            Sv pAi = {-1.0f * cross(C.P, dirs[a]), -1.0f * dirs[a]};
+            Sv pAi = {-1.0f * cross(Pc, dirs[a]), -1.0f * dirs[a]};
             float ui[J];
             if (!is_base) {
 #pragma unroll
                 for (int k = J - 1; k >= 0; --k) {
                     if (k <= jl) {
                         ui[k] = -sdot(S[k], pAi);
-                        pAi = pAi + (ui[k] / D[k]) * U[k];
+                        pAi = pAi + (ui[k] * iD[k]) * U[k];
                     } else ui[k] = 0.f;
                 }
             }
@@ -323,38 +337,37 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
 #pragma unroll
                 for (int k = 0; k < J; ++k)
                     if (k <= jl) {
-                        float dq = (ui[k] - sdot(U[k], dv)) / D[k];
+                        float dq = (ui[k] - sdot(U[k], dv)) * iD[k];
                         dv = dv + dq * S[k];
                     }
             }
-            V3 dvP = dv.v + cross(dv.w, C.P);
+            V3 dvP = dv.v + cross(dv.w, Pc);
 #pragma unroll
             for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
         }
-        C.W00 = Wc[0][0]; C.W10 = Wc[1][0]; C.W20 = Wc[2][0]; C.W11 = Wc[1][1]; C.W21 = Wc[2][1]; C.W22 = Wc[2][2];
+        CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
+        CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
+        CF(si, 6) = __frcp_rn(Wc[0][0]); CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
+        CF(si, 9) = __frcp_rn(Wc[1][1]); CF(si, 10) = Wc[2][1]; CF(si, 11) = __frcp_rn(Wc[2][2]);
+        CF(si, 12) = vtarget;
     }
-    {
-        const int n_base_active = (int)leg_sum<L>(ct[LG_MAX_LEG_SLOTS].active ? 1.0f : 0.0f);
-#pragma unroll
-        for (int s = 0; s < LG_MAX_LEG_SLOTS; ++s) ct[s].relax = ct[s].active ? 1.0f / (float)n_leg_active : 0.f;
-        ct[LG_MAX_LEG_SLOTS].relax = ct[LG_MAX_LEG_SLOTS].active ? 1.0f / (float)n_base_active : 0.f;
-    }
-    bool any_contact = false;
-#pragma unroll
-    for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) any_contact |= ct[s].active;
+    const bool base_active = (amask >> LG_MAX_LEG_SLOTS) & 1u;
+    const int n_base_active = (int)leg_sum<L>(base_active ? 1.0f : 0.0f);
+    const int n_leg_active = __popc(amask & ((1u << LG_MAX_LEG_SLOTS) - 1u));
+    const float rl = __frcp_rn((float)max(n_leg_active, 1)), rb = __frcp_rn((float)max(n_base_active, 1));
 
     // ---- projected Jacobi sweeps (wave-uniform trip count; contact-free waves skip them)
-    if (__any(any_contact)) {
+    if (__any(amask != 0u)) {
         for (int it = 0; it < c.solver_iterations; ++it) {
             Sv fimp[J], fb = sv_zero();
 #pragma unroll
             for (int k = 0; k < J; ++k) fimp[k] = sv_zero();
-#pragma unroll
-            for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) {
-                Contact &C = ct[s];
-                if (!__any(C.active)) continue;
-                const bool is_base = (s == LG_MAX_LEG_SLOTS);
-                const int jl = is_base ? 0 : P->slot_link[s < nslots ? s : 0];
+            for (int s = 0; s <= nslots; ++s) {
+                const bool is_base = (s == nslots);
+                const int si = is_base ? LG_MAX_LEG_SLOTS : s;
+                const bool active = (amask >> si) & 1u;
+                if (!__any(active)) continue;
+                const int jl = is_base ? 0 : P->slot_link[s];
                 Sv vl = velf0;
                 if (!is_base) {
                     vl = velf[0];
@@ -362,23 +375,25 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
                     for (int k = 1; k < J; ++k)
                         if (jl == k) vl = velf[k];
                 }
-                if (C.active) {
+                if (active) {
+                    const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
+                    const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
                     V3 t1, t2;
-                    tangents(C.n, t1, t2);
-                    V3 vP = vl.v + cross(vl.w, C.P);
-                    float vc0 = dot(C.n, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
-                    float ln = fmaxf(0.0f, C.ln - C.relax * (vc0 - C.vtarget) / C.W00);
-                    float dn = ln - C.ln;
-                    vc1 += C.W10 * dn;
-                    vc2 += C.W20 * dn;
-                    float l1 = C.l1 - C.relax * vc1 / C.W11;
-                    vc2 += C.W21 * (l1 - C.l1);
-                    float l2 = C.l2 - C.relax * vc2 / C.W22;
+                    tangents(nb, t1, t2);
+                    V3 vP = vl.v + cross(vl.w, Pc);
+                    float vc0 = dot(nb, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
+                    float ln = fmaxf(0.0f, oln - relax * (vc0 - CF(si, 12)) * CF(si, 6));
+                    float dn = ln - oln;
+                    vc1 += CF(si, 7) * dn;
+                    vc2 += CF(si, 8) * dn;
+                    float l1 = ol1 - relax * vc1 * CF(si, 9);
+                    vc2 += CF(si, 10) * (l1 - ol1);
+                    float l2 = ol2 - relax * vc2 * CF(si, 11);
                     float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
-                    if (mag > lim) { float sc = lim / fmaxf(mag, 1e-12f); l1 *= sc; l2 *= sc; }
-                    V3 dl = (ln - C.ln) * C.n + (l1 - C.l1) * t1 + (l2 - C.l2) * t2;
-                    C.ln = ln; C.l1 = l1; C.l2 = l2;
-                    Sv f = {cross(C.P, dl), dl};
+                    if (mag > lim) { float sc = lim * __frcp_rn(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
+                    V3 dl = (ln - oln) * nb + (l1 - ol1) * t1 + (l2 - ol2) * t2;
+                    CF(si, 13) = ln; CF(si, 14) = l1; CF(si, 15) = l2;
+                    Sv f = {cross(Pc, dl), dl};
                     if (is_base) fb = fb + f;
                     else {
 #pragma unroll
@@ -393,14 +408,14 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
             for (int k = J - 1; k >= 0; --k) {
                 Sv cur = run - fimp[k];
                 ui[k] = -sdot(S[k], cur);
-                run = cur + (ui[k] / D[k]) * U[k];
+                run = cur + (ui[k] * iD[k]) * U[k];
             }
             Sv pAi0 = leg_sum<L>(run - fb);
             Sv dv = -1.0f * mul6(I0inv, pAi0);
             velf0 = velf0 + dv;
 #pragma unroll
             for (int k = 0; k < J; ++k) {
-                float dq = (ui[k] - sdot(U[k], dv)) / D[k];
+                float dq = (ui[k] - sdot(U[k], dv)) * iD[k];
                 dv = dv + dq * S[k];
                 velf[k] = velf[k] + dv;
                 qdf[k] += dq;
@@ -410,16 +425,18 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
 
     // ---- contact forces out (world frame, N)
 #pragma unroll
-    for (int s = 0; s <= LG_MAX_LEG_SLOTS; ++s) {
+    for (int si = 0; si <= LG_MAX_LEG_SLOTS; ++si) {
         V3 f = {0.f, 0.f, 0.f};
-        const Contact &C = ct[s];
-        if (C.active) {
+        if ((amask >> si) & 1u) {
+            const V3 nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
             V3 t1, t2;
-            tangents(C.n, t1, t2);
-            f = (1.0f / dt) * mul(Rb, C.ln * C.n + C.l1 * t1 + C.l2 * t2);
+            tangents(nb, t1, t2);
+            f = inv_dt * mul(Rb, CF(si, 13) * nb + CF(si, 14) * t1 + CF(si, 15) * t2);
         }
-        if (s == LG_MAX_LEG_SLOTS) fbase = f; else fslot[s] = f;
+        if (si == LG_MAX_LEG_SLOTS) fbase = f; else fslot[si] = f;
     }
+#undef CF
+#undef LK
     if (!ok) return;                                        // degenerate model: leave the state untouched
     // ---- integrate
 #pragma unroll
@@ -446,7 +463,7 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
                    qq[3] * dq[1] - qq[0] * dq[2] + qq[1] * dq[3] + qq[2] * dq[0],
                    qq[3] * dq[2] + qq[0] * dq[1] - qq[1] * dq[0] + qq[2] * dq[3],
                    qq[3] * dq[3] - qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2]};
-    float nrm = 1.0f / sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    float nrm = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) qq[k] = qn[k] * nrm;
 }

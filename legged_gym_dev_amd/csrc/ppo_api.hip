@@ -98,11 +98,14 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1) {
             g.B[z] = l == 0 ? in[z] : n.act[l]; g.ldb[z] = n.dims[l];
             g.C[z] = p->dev.grads + n.w_off[l]; g.ldc[z] = n.dims[l];
             g.M[z] = n.dims[l + 1]; g.N[z] = n.dims[l]; g.K[z] = M;
-            long t = (long)((g.M[z] + 63) / 64) * ((g.N[z] + 63) / 64);
+            const int tile = (g.M[z] > 64 && g.N[z] > 64) ? 128 : 64;
+            long t = (long)((g.M[z] + tile - 1) / tile) * ((g.N[z] + tile - 1) / tile);
             tiles = t > tiles ? t : tiles;
         }
-        int splits = (int)((1024 + tiles - 1) / tiles);
-        int max_splits = M / 128 > 0 ? M / 128 : 1;
+        // ~256 workgroups per net: enough to fill the chip, few enough that the split-M float atomics
+        // (splits x output floats) stay well below the MFMA time
+        int splits = (int)((256 + tiles - 1) / tiles);
+        int max_splits = M / 256 > 0 ? M / 256 : 1;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         ppok_gemm_dw(&g, 2, splits, p->stream);

@@ -2,6 +2,8 @@
 // action sampling, GAE scan, PPO loss, grad-norm clip + Adam with the KL-adaptive learning rate
 // kept on the device.  Semantics: rsl_rl v1.0.2 (SURVEY.md Appendix B -- third-party, not in the
 // reference tree; call sites legged_gym/utils/task_registry.py:148-155).
+#include <cstring>
+
 #include "ppo_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -85,7 +87,7 @@ __device__ __forceinline__ float frag(const float *__restrict__ lds, int row, in
 template <bool RC, int ROWS>
 constexpr int tile_floats() { return RC ? ROWS * (BK + 1) : BK * (ROWS + 4); }
 
-template <bool A_RC, bool B_RC, int TM, int TN, bool VEC>
+template <bool A_RC, bool B_RC, int TM, int TN, bool VEC, bool DBUF>
 __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
                                               int M, int N, int k_begin, int k_end, float *__restrict__ lds, int wm, int wn, int li, int lk,
                                               f32x16 (&acc)[TM][TN]) {
@@ -105,7 +107,7 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const
             stage_load<A_RC, BM, VEC>(A, lda, m0, k0 + BK, M, k_end, ra, ma);
             stage_load<B_RC, BN, VEC>(B, ldb, n0, k0 + BK, N, k_end, rb, mb_);
         }
-        const float *as = lds + cur * (AF + BF), *bs = as + AF;
+        const float *as = lds + (DBUF ? cur : 0) * (AF + BF), *bs = as + AF;
         // fragments are fetched one group (GS k-steps) ahead of the MFMAs that consume them, so the
         // LDS latency is paid once per k-tile instead of once per k-step
         constexpr int GS = 4, NG = BK / 2 / GS;
@@ -137,9 +139,10 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gq & 1][s][a], bv[gq & 1][s][b], acc[a][b], 0, 0, 0);
         }
+        if (!DBUF) __syncthreads();              // single buffer: every wave is done reading before it is refilled
         if (more) {
-            stage_store<A_RC, BM>(lds + (cur ^ 1) * (AF + BF), ra, ma);
-            stage_store<B_RC, BN>(lds + (cur ^ 1) * (AF + BF) + AF, rb, mb_);
+            stage_store<A_RC, BM>(lds + (DBUF ? (cur ^ 1) : 0) * (AF + BF), ra, ma);
+            stage_store<B_RC, BN>(lds + (DBUF ? (cur ^ 1) : 0) * (AF + BF) + AF, rb, mb_);
         }
         __syncthreads();
         cur ^= 1;
@@ -147,7 +150,7 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const
 
 }
 
-template <bool A_RC, bool B_RC, int EPI, int TM, int TN>
+template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF>
 __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     const int z = blockIdx.z;
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (((B_RC ? k_end : N) & 3) == 0) && (B_RC ? k_end : N) >= 4;
 
     constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
-    __shared__ float lds[2 * (AF + BF)];
+    __shared__ float lds[(DBUF ? 2 : 1) * (AF + BF)];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
@@ -186,8 +189,8 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (a_vec && b_vec) gemm_mainloop<A_RC, B_RC, TM, TN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
-    else gemm_mainloop<A_RC, B_RC, TM, TN, false>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
+    if (a_vec && b_vec) gemm_mainloop<A_RC, B_RC, TM, TN, true, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
+    else gemm_mainloop<A_RC, B_RC, TM, TN, false, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
 
     // ---- epilogue.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *__restrict__ C = g.C[z];
@@ -267,18 +270,22 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     }
 }
 
+static int g_gemm_dbuf = 0;   // single LDS buffer (34 KB, 4 workgroups/CU) measured 3-15 % faster than double buffering
+extern "C" void ppok_debug_set_dbuf(int v) { g_gemm_dbuf = v; }
+
 template <bool A_RC, bool B_RC, int EPI>
 static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
     int maxM = 0, maxN = 0;
     for (int z = 0; z < nz; ++z) { maxM = g.M[z] > maxM ? g.M[z] : maxM; maxN = g.N[z] > maxN ? g.N[z] : maxN; }
     // small problems (rollout forward on 4096 rows, heads) use 64x64 tiles to fill more CUs
     const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
-    if (big_tiles * splits >= 192 && maxN > 64) {
+    if (big_tiles * splits >= 192 && maxN > 64 && maxM > 64) {
         dim3 grid((unsigned)big_tiles, splits, nz);
-        hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2>), grid, dim3(256), 0, s, g);
+        if (g_gemm_dbuf) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), splits, nz);
-        hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, true>), grid, dim3(256), 0, s, g);
     }
 }
 extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) { launch_gemm<true, true, 0>(*g, nz, 1, s); }
@@ -584,4 +591,15 @@ void ppok_step(const PpoDev *P, hipStream_t s) {
     hipLaunchKernelGGL(k_adam, dim3(256), dim3(256), 0, s, *P);
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, *P);
 }
+}
+
+// Debug / microbenchmark entry (tools/gemm_bench.py): C[M,N] = A . B with the layouts of `mode`
+// (0: A[m][k] B[n][k] forward; 1: A[m][k] B[k][n] input-gradient; 2: A[k][m] B[k][n] weight-gradient, C zeroed by caller).
+extern "C" void ppok_debug_gemm(const float *A, const float *B, float *C, int M, int N, int K, int mode, int splits, void *stream) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = A; g.B[0] = B; g.C[0] = C; g.M[0] = M; g.N[0] = N; g.K[0] = K; g.ldc[0] = N;
+    if (mode == 0) { g.lda[0] = K; g.ldb[0] = K; launch_gemm<true, true, 0>(g, 1, 1, (hipStream_t)stream); }
+    else if (mode == 1) { g.lda[0] = K; g.ldb[0] = N; g.aux[0] = C; g.ldaux[0] = N; launch_gemm<true, false, 1>(g, 1, 1, (hipStream_t)stream); }
+    else { g.lda[0] = M; g.ldb[0] = N; launch_gemm<false, false, 2>(g, 1, splits, (hipStream_t)stream); }
 }

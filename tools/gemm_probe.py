@@ -21,3 +21,15 @@ for k in range(reps):
 e1.record()
 torch.cuda.synchronize()
 print("ms per minibatch fwd+bwd:", e0.elapsed_time(e1) / reps)
+if len(sys.argv) > 3:
+    import ctypes
+    for v in (0, 1, 0, 1):
+        ppo.lib.ppok_debug_set_dbuf(ctypes.c_int(v))
+        ppo._call("minibatch_backward", 0, 0)
+        torch.cuda.synchronize()
+        e0.record()
+        for k in range(reps):
+            ppo._call("minibatch_backward", 0, k % 4)
+        e1.record()
+        torch.cuda.synchronize()
+        print("dbuf", v, "ms:", e0.elapsed_time(e1) / reps)

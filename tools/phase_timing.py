@@ -32,7 +32,7 @@ timeit("set_actions only", lambda: env.core.call("set_actions", __import__("ctyp
 timeit("compute_torques only", lambda: env.core.call("compute_torques"))
 timeit("simulate only", lambda: env.core.call("simulate"))
 timeit("post_physics_step only", lambda: env.core.call("post_physics_step"))
-ppo._call("end_update"); timeit("rollout() whole", lambda: runner.rollout(), n=1)
+timeit("rollout() whole", lambda: (ppo._call("end_update"), runner.rollout()), n=1)
 ppo._call("begin_update")
 timeit("minibatch_backward", lambda: ppo._call("minibatch_backward", 0, 0), n=4)
 timeit("minibatch_step", lambda: ppo._call("minibatch_step"), n=4)
