@@ -120,7 +120,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     DA(b.friction, N); DA(b.base_mass_delta, N);
     DA(b.extras_episode, LG_NUM_REWARDS); DA(b.extras_terrain_level, 1); DA(b.extras_time_outs, N); DA(b.n_reset, 1);
     DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N);
-    DA(h.ep_accum, LG_NUM_REWARDS); DA(h.reset_count, 1);
+    DA(h.ep_accum, LG_NUM_REWARDS); DA(h.reset_count, 1); DA(h.fault, N);
     {   // defaults: identity quaternion, unit friction, reset flags = 1 (base_task.py:72)
         float *tmp = new float[(size_t)N * 13]();
         for (int i = 0; i < N; ++i) tmp[(size_t)i * 13 + 6] = 1.0f;

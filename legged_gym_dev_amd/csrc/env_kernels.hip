@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(64, 1) k_physics(const DevParams *__restrict__
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
     for (int s = 0; s < ns; ++s) {
         V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-        physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk);
+        const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk);
+        if (fault && live && leg == 0) P->fault[env] = 1;
         V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
         if (live) {
 #pragma unroll
@@ -465,6 +466,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         }
         bool rst = false;                                                   // LR:139-145
         for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
+        if (P->fault[i]) { rst = true; P->fault[i] = 0; }               // physics fault guard (lg_physics.h)
         const bool to = ep > c.max_episode_length;
         rst = rst || to;
         P->buf.time_out[i] = to;

@@ -20,6 +20,7 @@ struct DevParams {
     const int16_t *height_samples; // hf_rows x hf_cols
     float *ep_accum;               // LG_NUM_REWARDS sums of episode_sums over resetting envs
     int32_t *reset_count;          // 1
+    uint8_t *fault;                // N: set by the physics fault guard, consumed by the post-step
     int K;                         // uniforms per env
     // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
     int n_leg_slots, n_base_spheres;

@@ -154,7 +154,7 @@ __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
 //   root[13] (world: pos, quat xyzw, lin vel, ang vel), q[J], qd[J] of this leg's joints.
 // fslot[s] / fbase receive the world-frame contact force (N) of this lane's sphere slots.
 template <int L, int J>
-__device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
+__device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
                                              float *qd, const float *tau, float friction, float dmass,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt) {
     const lg_cfg &c = P->cfg;
@@ -347,8 +347,9 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
         }
         CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
         CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
-        CF(si, 6) = __frcp_rn(Wc[0][0]); CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
-        CF(si, 9) = __frcp_rn(Wc[1][1]); CF(si, 10) = Wc[2][1]; CF(si, 11) = __frcp_rn(Wc[2][2]);
+        CF(si, 6) = Wc[0][0] > 1e-9f ? __frcp_rn(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
+        CF(si, 9) = Wc[1][1] > 1e-9f ? __frcp_rn(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
+        CF(si, 11) = Wc[2][2] > 1e-9f ? __frcp_rn(Wc[2][2]) : 0.f;
         CF(si, 12) = vtarget;
     }
     const bool base_active = (amask >> LG_MAX_LEG_SLOTS) & 1u;
@@ -437,7 +438,20 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
     }
 #undef CF
 #undef LK
-    if (!ok) return;                                        // degenerate model: leave the state untouched
+    // ---- fault guard (PhysX never hands back non-finite or absurd state; neither may we): an env whose
+    // solve produced NaN/Inf or a base twist beyond 100 m/s | rad/s keeps its pose, is brought to rest and
+    // is reported so that the post-step terminates and resets it.
+    float chk = dot(velf0.w, velf0.w) + dot(velf0.v, velf0.v);
+#pragma unroll
+    for (int j = 0; j < J; ++j) chk += qdf[j] * qdf[j] * 1e-4f;
+    chk = leg_sum<L>(chk);
+    if (!ok || !(chk < 2.0e4f)) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) qd[j] = 0.f;
+#pragma unroll
+        for (int k = 7; k < 13; ++k) root[k] = 0.f;
+        return true;
+    }
     // ---- integrate
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -466,4 +480,5 @@ __device__ __forceinline__ void physics_lane(const DevParams *__restrict__ P, in
     float nrm = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) qq[k] = qn[k] * nrm;
+    return false;
 }

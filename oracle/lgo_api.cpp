@@ -42,7 +42,7 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
     z(e->extras_terrain_level, 1); z(e->inj_u, (size_t)N * e->K);
     for (int i = 0; i < N; ++i) { e->root[(size_t)i * 13 + 6] = 1.0f; e->friction[i] = 1.0f; }
     e->reset.assign(N, 1); e->time_out.assign(N, 0); e->last_contacts.assign((size_t)N * F, 0);
-    e->extras_time_outs.assign(N, 0); e->ep_len.assign(N, 0); e->terrain_levels.assign(N, 0);
+    e->extras_time_outs.assign(N, 0); e->fault.assign(N, 0); e->ep_len.assign(N, 0); e->terrain_levels.assign(N, 0);
     e->terrain_types.assign(N, 0); e->inj_levels.assign(N, 0); e->n_reset.assign(1, 0);
     *out = e;
     return 0;

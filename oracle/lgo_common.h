@@ -47,7 +47,7 @@ struct Env {
     std::vector<float> root, dof, contact, torques, actions, obs, rew, commands, last_actions, last_dof_vel,
         last_root_vel, feet_air_time, episode_sums, base_lin_vel, base_ang_vel, proj_grav, heights,
         env_origins, lstm_h, lstm_c, friction, base_mass_delta, extras_episode, extras_terrain_level, inj_u;
-    std::vector<uint8_t> reset, time_out, last_contacts, extras_time_outs;
+    std::vector<uint8_t> reset, time_out, last_contacts, extras_time_outs, fault;
     std::vector<int64_t> ep_len, terrain_levels, terrain_types, inj_levels;
     std::vector<int32_t> n_reset;
     int64_t step_counter = 0;

@@ -266,6 +266,7 @@ void post_physics_step(Env &e) {
         // ---- check_termination LR:139-145
         bool rst = false;
         for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
+        if (e.fault[i]) { rst = true; e.fault[i] = 0; }              // physics fault guard (lgo_physics.cpp)
         bool to = e.ep_len[i] > c.max_episode_length;
         e.time_out[i] = to;
         e.reset[i] = rst || to;

@@ -132,10 +132,10 @@ struct Contact {
     V3 P, n, t1, t2;           // base coords
     float W[3][3];             // contact frame (n,t1,t2)
     float vtarget, mu, relax;
-    float lam[3];
+    float lam[3], iW[3];
 };
 
-static void simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weight) {
+static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weight) {
     const lg_cfg &c = e.cfg;
     const lg_model &m = e.model;
     const int A = e.A, NL = A + 1;
@@ -199,7 +199,8 @@ static void simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
         pA[pl] = pA[pl] + pa;
     }
     M6 I0inv;
-    if (!spd_inverse6(IA[0], I0inv)) return;                            // degenerate model: leave state untouched
+    const bool ok = spd_inverse6(IA[0], I0inv);
+    if (!ok) { for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) I0inv.m[a][b] = 0.f; }
     acc[0] = -1.0f * mul(I0inv, pA[0]);
     for (int d = 0; d < A; ++d) {                                       // outward pass
         Sv ap = acc[par[d]] + cb[d];
@@ -264,6 +265,7 @@ static void simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
             V3 dvP = dv[l].v + cross(dv[l].w, C.P);
             for (int b = 0; b < 3; ++b) C.W[b][a] = dot(dirs[b], dvP);
         }
+        for (int a = 0; a < 3; ++a) C.iW[a] = C.W[a][a] > 1e-9f ? 1.0f / C.W[a][a] : 0.0f;
     }
     for (int k = 0; k < nc; ++k) ct[k].relax = 1.0f / (float)group_count[ct[k].group];
 
@@ -275,13 +277,13 @@ static void simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
             V3 vP = velf[C.link].v + cross(velf[C.link].w, C.P);
             float vc[3] = {dot(C.n, vP), dot(C.t1, vP), dot(C.t2, vP)};
             float old[3] = {C.lam[0], C.lam[1], C.lam[2]};
-            float ln = std::max(0.0f, old[0] - C.relax * (vc[0] - C.vtarget) / C.W[0][0]);
+            float ln = std::max(0.0f, old[0] - C.relax * (vc[0] - C.vtarget) * C.iW[0]);
             float dn = ln - old[0];
             vc[1] += C.W[1][0] * dn;
             vc[2] += C.W[2][0] * dn;
-            float l1 = old[1] - C.relax * vc[1] / C.W[1][1];
+            float l1 = old[1] - C.relax * vc[1] * C.iW[1];
             vc[2] += C.W[2][1] * (l1 - old[1]);
-            float l2 = old[2] - C.relax * vc[2] / C.W[2][2];
+            float l2 = old[2] - C.relax * vc[2] * C.iW[2];
             float lim = C.mu * ln, mag = std::sqrt(l1 * l1 + l2 * l2);
             if (mag > lim) { float s = lim / std::max(mag, 1e-12f); l1 *= s; l2 *= s; }
             C.lam[0] = ln; C.lam[1] = l1; C.lam[2] = l2;
@@ -303,6 +305,15 @@ static void simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
         cf_accum[3 * C.body + 0] += s * lw.x;
         cf_accum[3 * C.body + 1] += s * lw.y;
         cf_accum[3 * C.body + 2] += s * lw.z;
+    }
+    // fault guard (same rule as the HIP kernel): NaN/Inf or an absurd base twist -> keep the pose, bring the
+    // env to rest, report the fault (the post-step then terminates and resets it)
+    float chk = dot(velf[0].w, velf[0].w) + dot(velf[0].v, velf[0].v);
+    for (int d = 0; d < A; ++d) chk += qdf[d] * qdf[d] * 1e-4f;
+    if (!ok || !(chk < 2.0e4f)) {
+        for (int d = 0; d < A; ++d) dofs[2 * d + 1] = 0.0f;
+        for (int k = 7; k < 13; ++k) root[k] = 0.0f;
+        return true;
     }
     for (int d = 0; d < A; ++d) {
         float v = qdf[d];
@@ -328,6 +339,7 @@ static void simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
                    q[3] * dq[3] - q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2]};
     float nrm = 1.0f / std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     for (int k = 0; k < 4; ++k) q[k] = qn[k] * nrm;
+    return false;
 }
 
 void simulate(Env &e) {
@@ -338,7 +350,8 @@ void simulate(Env &e) {
     for (int i = 0; i < N; ++i) {
         float *cf = &e.contact[(size_t)i * B * 3];
         for (int k = 0; k < 3 * B; ++k) cf[k] = 0.0f;
-        for (int s = 0; s < ns; ++s) simulate_env(e, i, dt, cf, 1.0f / (float)ns);
+        for (int s = 0; s < ns; ++s)
+            if (simulate_env(e, i, dt, cf, 1.0f / (float)ns)) e.fault[i] = 1;
     }
 }
 

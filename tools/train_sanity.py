@@ -1,0 +1,62 @@
+"""End-to-end learning sanity on the GPU.
+
+    python tools/train_sanity.py ITERS [HIDDEN] [MODE]
+
+MODE "ref"  : the fork's anymal_c_flat config as committed (its reward is identically 0 after the
+              positive clip: commands x,y are 0 so feet_air_time never pays).
+MODE "walk" : same env with ETH legged_gym's default velocity-tracking reward table and command
+              ranges -- a task with a learning signal, to show that rollout + physics + PPO learn.
+Prints the learning curve (mean episode return / length of the episodes finished in each window).
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+hidden = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "128,64,32").split(",")]
+mode = sys.argv[3] if len(sys.argv) > 3 else "walk"
+
+from legged_gym_dev_amd.envs.anymal_c.anymal import Anymal
+from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
+from legged_gym_dev_amd.rl.runner import OnPolicyRunner
+from legged_gym_dev_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
+
+env_cfg, train_cfg = AnymalCFlatCfg(), AnymalCFlatCfgPPO()
+env_cfg.env.num_envs = 4096
+env_cfg.seed = 1
+if mode == "walk":
+    r = env_cfg.commands.ranges
+    r.lin_vel_x, r.lin_vel_y, r.ang_vel_yaw = [-1.0, 1.0], [-1.0, 1.0], [-1.5, 1.5]
+    sc = env_cfg.rewards.scales
+    for k, v in dict(tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_vel_z=-2.0, ang_vel_xy=-0.05, dof_acc=-2.5e-7,
+                     collision=-1.0, action_rate=-0.01, orientation=-5.0, torques=-0.000025, feet_air_time=2.0).items():
+        setattr(sc, k, v)
+train_cfg.policy.actor_hidden_dims = list(hidden)
+train_cfg.policy.critic_hidden_dims = list(hidden)
+args = get_args([])
+args.sim_device = args.rl_device = "cuda:0"
+torch.manual_seed(1)
+np.random.seed(1)
+env = Anymal(env_cfg, parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)}), args.physics_engine, "cuda:0", True)
+runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device="cuda:0")
+ppo = runner.ppo
+env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+t0 = time.time()
+for it in range(iters):
+    runner.rollout()
+    vl, sl = ppo.update()
+    if it % 25 == 24 or it == 0:
+        es = ppo.t["ep_stats"].cpu().tolist()
+        ppo.t["ep_stats"].zero_()
+        n = max(es[2], 1)
+        bad = int((~torch.isfinite(env.root_states).all(1)).sum()) + int((~torch.isfinite(env.obs_buf).all(1)).sum())
+        trk = float(env.extras["episode"].get("rew_tracking_lin_vel", torch.zeros(()))) if "episode" in env.extras else 0.0
+        print(f"it {it + 1:4d}  mean_return {es[0] / n:8.3f}  mean_ep_len {es[1] / n:7.1f}  episodes {int(es[2]):6d}  "
+              f"std {float(ppo.param_views['std'].mean()):.3f} lr {ppo.learning_rate:.2e} vloss {float(vl):.4f}  "
+              f"base_z {float(env.root_states[:, 2].mean()):.3f} rew_tracking_lin_vel {trk:.4f} nonfinite_envs {bad}", flush=True)
+dt = time.time() - t0
+print(f"{iters} iterations in {dt:.1f}s -> {iters * 24 * 4096 / dt:.0f} env-steps/s incl. logging")
