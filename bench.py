@@ -193,10 +193,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # rehearsal knobs (1-GPU box): LG_BENCH_BACKEND=gloo LG_BENCH_SHARE_GPU=1 run all ranks on cuda:0 over gloo
+    backend = os.environ.get("LG_BENCH_BACKEND", "nccl")
+    if os.environ.get("LG_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            torch.distributed.init_process_group(backend)
     env, runner = make_runner(args.num_envs, hidden, device, rank, world)
     el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world
