@@ -514,6 +514,227 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused head: [actor head 128->A | critic head 128->1] forward + PPO loss + head backward, one
+// workgroup per 64 minibatch rows.  Replaces four launches (head GEMM, k_loss, head weight-gradient
+// GEMM, head input-gradient GEMM) whose matrices are too thin for the MFMA tiles: the last hidden
+// activations of both nets are staged once in LDS and reused for mu/V, for d(loss)/d(act3) and for
+// the outer-product weight gradients.  H3 = last hidden width (<= 128).
+#define HEAD_ROWS 64
+#define HEAD_GRID 192
+template <int H3>
+__global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__restrict__ xa_g, const float *__restrict__ xc_g,
+                                                    float *__restrict__ dza_g, float *__restrict__ dzc_g, int64_t w_a, int64_t b_a,
+                                                    int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c) {
+    constexpr int MA = LG_PPO_MAX_A, LDX = H3 + 1, NH = 256 / H3;   // NH row groups run concurrently in the backward part
+    const int R = P.mb_rows, A = P.A, tid = threadIdx.x;
+    __shared__ float xa[HEAD_ROWS * LDX], xc[HEAD_ROWS * LDX];
+    __shared__ float wa[MA * H3], wc[H3];
+    __shared__ float mus[HEAD_ROWS][MA + 1], dmus[HEAD_ROWS][MA + 1];    // [..][MA]: value / d value
+    // per-action constants of the Gaussian terms (row independent): sigma_old^2, 1/(2 s^2), 1/s^2, 1/s, ln s + ln sqrt(2 pi),
+    // ln(s / s_old + 1e-5) -- so the per-row loss needs no log and no division
+    __shared__ float red[2 * MA + 4], s_so2[MA], s_i2s2[MA], s_is2[MA], s_is[MA], s_lgs[MA], s_klc[MA];
+    if (tid < MA) {
+        const float sg = tid < A ? P.params[P.off_std + tid] : 1.f, so = tid < A ? P.st_sigma[tid] : 1.f;
+        s_so2[tid] = so * so; s_i2s2[tid] = 1.0f / (2.0f * sg * sg); s_is2[tid] = 1.0f / (sg * sg); s_is[tid] = 1.0f / sg;
+        s_lgs[tid] = logf(sg) + 0.9189385332046727f; s_klc[tid] = logf(sg / so + 1.e-5f) - 0.5f;
+    }
+    for (int i = tid; i < A * H3; i += 256) wa[i] = P.params[w_a + i];
+    for (int i = tid; i < H3; i += 256) wc[i] = P.params[w_c + i];
+    if (tid < 2 * MA + 4) red[tid] = 0.f;
+    // backward accumulators of this thread's column, kept in registers across all row tiles of the block
+    const int c = tid % H3, half = tid / H3;
+    float dwa[MA], dwc = 0.f, dba = 0.f, dbc = 0.f, part[2 * MA + 4];
+#pragma unroll
+    for (int a = 0; a < MA; ++a) dwa[a] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * MA + 4; ++k) part[k] = 0.f;
+    const int ntiles = (R + HEAD_ROWS - 1) / HEAD_ROWS;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = tile * HEAD_ROWS;
+        __syncthreads();                                   // previous tile fully consumed (also covers the weight staging)
+        {   // stage both activation tiles: unconditional 16-byte loads from clamped rows (rows past R are
+            // never used: every consumer below checks r < R), issued as one batch
+            constexpr int NV = HEAD_ROWS * H3 / 4 / 256;
+            float4 va[NV], vc[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = tid + v * 256, r = i / (H3 / 4), c4 = i % (H3 / 4);
+                const size_t row = (size_t)min(r0 + r, R - 1);
+                va[v] = *reinterpret_cast<const float4 *>(xa_g + row * H3 + 4 * c4);
+                vc[v] = *reinterpret_cast<const float4 *>(xc_g + row * H3 + 4 * c4);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the 2*NV loads in flight together (hipcc otherwise pairs each with its LDS store)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = tid + v * 256, r = i / (H3 / 4), c4 = i % (H3 / 4);
+                float *da = xa + r * LDX + 4 * c4, *dc = xc + r * LDX + 4 * c4;
+                da[0] = va[v].x; da[1] = va[v].y; da[2] = va[v].z; da[3] = va[v].w;
+                dc[0] = vc[v].x; dc[1] = vc[v].y; dc[2] = vc[v].z; dc[3] = vc[v].w;
+            }
+        }
+        __syncthreads();
+        {   // head forward: lane = row (conflict-free x reads, broadcast weight reads); wave w -> outputs w, w+4, w+8, w+12
+            const int r = tid & 63, w = tid >> 6;
+            const float *x = xa + r * LDX;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            const float *w0 = wa + (w < A ? w : 0) * H3, *w1 = wa + (w + 4 < A ? w + 4 : 0) * H3;
+            const float *w2 = wa + (w + 8 < A ? w + 8 : 0) * H3, *w3 = wa + (w + 12 < A ? w + 12 : 0) * H3;
+#pragma unroll 8
+            for (int k = 0; k < H3; ++k) {
+                const float xv = x[k];
+                o0 += xv * w0[k]; o1 += xv * w1[k]; o2 += xv * w2[k]; o3 += xv * w3[k];
+            }
+            if (w < A) mus[r][w] = o0 + P.params[b_a + w];
+            if (w + 4 < A) mus[r][w + 4] = o1 + P.params[b_a + w + 4];
+            if (w + 8 < A) mus[r][w + 8] = o2 + P.params[b_a + w + 8];
+            if (w + 12 < A) mus[r][w + 12] = o3 + P.params[b_a + w + 12];
+            if (w == 3) {                                  // wave 3 carries the fewest actor outputs: it also does the value
+                float sacc = P.params[b_c];
+                const float *y = xc + r * LDX;
+#pragma unroll 8
+                for (int k = 0; k < H3; ++k) sacc += y[k] * wc[k];
+                mus[r][MA] = sacc;
+            }
+        }
+        __syncthreads();
+        if (tid < HEAD_ROWS) {   // loss of one row (same arithmetic as k_loss), wave 0 only; partials stay in registers
+            const int r = r0 + tid;
+            const float invR = 1.0f / (float)R;
+            float dvl = 0.f;
+#pragma unroll
+            for (int a = 0; a < MA; ++a) dmus[tid][a] = 0.f;
+            // operands of this row: unconditional loads from a clamped row / action index, issued up front
+            const size_t rr = (size_t)min(r, R - 1);
+            const float4 sc = reinterpret_cast<const float4 *>(P.mb_scalars)[rr];
+            float act_r[MA], mo_r[MA];
+#pragma unroll
+            for (int a = 0; a < MA; ++a) {
+                const int ac = min(a, A - 1);
+                act_r[a] = P.mb_actions[rr * A + ac];
+                mo_r[a] = P.mb_mu[rr * A + ac];
+            }
+            if (r < R) {
+                const float v_old = sc.x, ret = sc.y, adv = sc.z, lp_old = sc.w;
+                float lp = 0.f, kl = 0.f, dd[MA];
+#pragma unroll
+                for (int a = 0; a < MA; ++a) {
+                    dd[a] = 0.f;
+                    if (a < A) {
+                        const float m = mus[tid][a], mo = mo_r[a];
+                        const float d = act_r[a] - m;
+                        dd[a] = d;
+                        lp += -(d * d) * s_i2s2[a] - s_lgs[a];
+                        kl += s_klc[a] + (s_so2[a] + (mo - m) * (mo - m)) * s_i2s2[a];
+                    }
+                }
+                const float ratio = expf(lp - lp_old);
+                const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+                const float s1 = -adv * ratio, s2 = -adv * rc;
+                const float dl_dlp = (s1 >= s2 ? -adv : 0.0f) * ratio * invR;
+#pragma unroll
+                for (int a = 0; a < MA; ++a)
+                    if (a < A) {
+                        const float d = dd[a];
+                        const float g = dl_dlp * d * s_is2[a];
+                        dmus[tid][a] = g;
+                        part[MA + a] += g;
+                        part[a] += dl_dlp * (d * d * s_is2[a] * s_is[a] - s_is[a]) - P.entropy_coef * invR * s_is[a];
+                    }
+                const float v = mus[tid][MA];
+                float lv, dv;
+                if (P.clipped_value) {
+                    const float dvv = v - v_old;
+                    const float vc = v_old + fminf(fmaxf(dvv, -P.clip), P.clip);
+                    const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+                    const float inside = (dvv >= -P.clip && dvv <= P.clip) ? 1.0f : 0.0f;
+                    lv = fmaxf(l1, l2);
+                    if (l1 > l2) dv = 2.0f * (v - ret);
+                    else if (l1 < l2) dv = 2.0f * (vc - ret) * inside;
+                    else dv = (v - ret) + (vc - ret) * inside;
+                } else {
+                    lv = (ret - v) * (ret - v);
+                    dv = 2.0f * (v - ret);
+                }
+                dvl = dv * P.value_coef * invR;
+                part[2 * MA] += dvl;
+                part[2 * MA + 1] += kl;
+                part[2 * MA + 2] += lv;
+                part[2 * MA + 3] += fmaxf(s1, s2);
+            }
+            dmus[tid][MA] = dvl;
+        }
+        __syncthreads();
+        // head backward for column c: dz3 = (dmu . W) * ELU'(act3) ; dW += dmu^T act3 ; colsum(dz3) -> previous bias grad
+        if (half < NH) {
+            float wcol[MA];
+#pragma unroll
+            for (int a = 0; a < MA; ++a) wcol[a] = a < A ? wa[a * H3 + c] : 0.f;
+            const float wcc = wc[c];
+            for (int r = half; r < HEAD_ROWS && r0 + r < R; r += NH) {
+                float g = 0.f;
+                const float x = xa[r * LDX + c], y = xc[r * LDX + c];
+#pragma unroll
+                for (int a = 0; a < MA; ++a) {
+                    const float dm = dmus[r][a];
+                    g += dm * wcol[a];
+                    dwa[a] += dm * x;
+                }
+                const float dz = g * (x > 0.f ? 1.0f : x + 1.0f);
+                const float dv = dmus[r][MA];
+                const float dzc = dv * wcc * (y > 0.f ? 1.0f : y + 1.0f);
+                dza_g[(size_t)(r0 + r) * H3 + c] = dz;
+                dzc_g[(size_t)(r0 + r) * H3 + c] = dzc;
+                dwc += dv * y;
+                dba += dz;
+                dbc += dzc;
+            }
+        }
+    }
+    // ---- flush: loss partials (wave 0), then column accumulators reduced over the NH row groups through LDS
+    if (tid < HEAD_ROWS) {
+#pragma unroll
+        for (int k = 0; k < 2 * MA + 4; ++k) {
+            if (k >= 2 * MA || (k % MA) < A) {
+                float v = part[k];
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+                if (tid == 0) red[k] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * MA + 4 && (tid >= 2 * MA || (tid % MA) < A)) {
+        const int k = tid;
+        const float v = red[k];
+        if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
+        else if (k < 2 * MA) atomicAdd(&P.grads[b_a + (k - MA)], v);
+        else if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
+        else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);
+        else if (k == 2 * MA + 2) atomicAdd(&P.loss_acc[0], v);
+        else atomicAdd(&P.loss_acc[1], v);
+    }
+    float *acc = xa;                                      // reuse the tile buffer: [MA + 3][NH][H3]
+    __syncthreads();
+    if (half < NH) {
+#pragma unroll
+        for (int a = 0; a < MA; ++a) acc[(a * NH + half) * H3 + c] = dwa[a];
+        acc[((MA + 0) * NH + half) * H3 + c] = dwc;
+        acc[((MA + 1) * NH + half) * H3 + c] = dba;
+        acc[((MA + 2) * NH + half) * H3 + c] = dbc;
+    }
+    __syncthreads();
+    for (int i = tid; i < (MA + 3) * H3; i += 256) {
+        const int q = i / H3, cc = i % H3;
+        float v = 0.f;
+        for (int h = 0; h < NH; ++h) v += acc[(q * NH + h) * H3 + cc];
+        if (q < MA) { if (q < A) atomicAdd(&P.grads[w_a + (int64_t)q * H3 + cc], v); }
+        else if (q == MA) atomicAdd(&P.grads[w_c + cc], v);
+        else if (q == MA + 1) atomicAdd(&P.grads[b_prev_a + cc], v);
+        else atomicAdd(&P.grads[b_prev_c + cc], v);
+    }
+}
+
 // KL-adaptive learning rate (rsl_rl PPO.update) + reset of the norm accumulator
 __global__ void k_pre_step(PpoDev P) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -581,6 +802,17 @@ void ppok_adv_normalize(const PpoDev *P, hipStream_t s) {
 }
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
     hipLaunchKernelGGL(k_gather, dim3(P->mb_rows), dim3(64), 0, s, *P, mb);
+}
+// returns 0 when the fused head kernel supports this width, -1 otherwise (caller falls back to GEMMs + k_loss)
+int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
+                    int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c, hipStream_t s) {
+    const int ntiles = (P->mb_rows + HEAD_ROWS - 1) / HEAD_ROWS;
+    dim3 grid(ntiles < HEAD_GRID ? ntiles : HEAD_GRID), block(256);
+    if (H3 == 128) hipLaunchKernelGGL((k_head_fused<128>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+    else if (H3 == 64) hipLaunchKernelGGL((k_head_fused<64>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+    else if (H3 == 32) hipLaunchKernelGGL((k_head_fused<32>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+    else return -1;
+    return 0;
 }
 void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s) {
     hipLaunchKernelGGL(k_loss, dim3((P->mb_rows + 255) / 256), dim3(256), 0, s, *P, mu, v, dmu, dval);
