@@ -299,7 +299,7 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     const int nl = na.nl, H3 = na.dims[nl - 1];
     // fused head (forward + loss + backward of the two thin head layers) when both nets end in the same
     // supported width; otherwise head GEMMs + k_loss
-    const bool fuse = nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32)  // at 128 the head GEMMs + k_loss measured faster (0.755 vs 0.773 ms per minibatch);
+    const bool fuse = nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32);   // at 128 the head GEMMs + k_loss measured faster (0.755 vs 0.773 ms)
     forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],
