@@ -37,6 +37,9 @@ struct lg_ppo {
     PpoDev dev;
     Net net[2];                              // 0 actor, 1 critic
     hipStream_t stream;
+    hipStream_t side;                        // weight-gradient GEMMs run here, overlapping the input-gradient chain
+    hipEvent_t ev_dz, ev_side;
+    int overlap;
     int step, inject;
     int64_t act_count, update_count;
     int Mmax;
@@ -110,7 +113,13 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         int max_splits = M / 256 > 0 ? M / 256 : 1;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
-        ppok_gemm_dw(&g, 2, splits, p->stream);
+        if (p->overlap) {                            // dz[l+1] is complete on the main stream at this point
+            (void)hipEventRecord(p->ev_dz, p->stream);
+            (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
+            ppok_gemm_dw(&g, 2, splits, p->side);
+        } else {
+            ppok_gemm_dw(&g, 2, splits, p->stream);
+        }
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * ELU'(act[l]); db_{l-1} = colsum(dz[l])
             memset(&g, 0, sizeof(g));
             for (int z = 0; z < 2; ++z) {
@@ -125,12 +134,19 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
             ppok_gemm_dx(&g, 2, p->stream);
         }
     }
+    if (p->overlap) {                                // join: the optimiser step (main stream) needs every dW
+        (void)hipEventRecord(p->ev_side, p->side);
+        (void)hipStreamWaitEvent(p->stream, p->ev_side, 0);
+    }
 }
 
 extern "C" {
 
 int lg_ppo_destroy(lg_ppo *p) {
     if (!p) return 0;
+    if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
+    if (p->ev_dz) (void)hipEventDestroy(p->ev_dz);
+    if (p->ev_side) (void)hipEventDestroy(p->ev_side);
     for (void *q : p->allocs) (void)hipFree(q);
     delete p;
     return 0;
@@ -150,6 +166,12 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     lg_ppo *p = new lg_ppo();
     p->cfg = *cfg;
     p->stream = nullptr;
+    p->overlap = 1;
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming) != hipSuccess) {
+        lg_set_error("stream/event creation failed"); delete p; return -100;
+    }
     p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0;
     p->perm_state = cfg->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
     const int R = (int)((long)N * T / cfg->num_mini_batches);
@@ -224,6 +246,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
 int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out) { *out = p->pub; return 0; }
 int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0; }
 int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
+int lg_ppo_debug_set_overlap(lg_ppo *p, int v) { p->overlap = v; return 0; }
 
 // entries: std, then per net per layer (W, b).  offsets[i]; shapes[2i] = rows, shapes[2i+1] = cols (0 for vectors)
 int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_entries) {
