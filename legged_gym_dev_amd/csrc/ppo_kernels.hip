@@ -21,19 +21,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // EPI 2: C += acc via float atomics, reduction split over blockIdx.y   (weight gradient)
 #define BK 32
 
-template <bool RC, int ROWS, bool VEC>
+template <bool RC, int ROWS, bool VEC, bool KSEQ = false, int NT = 256>
 __device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld, int row0, int red0, int nrows, int nred,
-                                           float4 (&regs)[ROWS * BK / 4 / 256], unsigned &mask) {
-    constexpr int NV = ROWS * BK / 4 / 256;
+                                           float4 (&regs)[ROWS * BK / 4 / NT], unsigned &mask) {
+    constexpr int NV = ROWS * BK / 4 / NT;
     const int tid = threadIdx.x;
     const int row_lim = RC ? nrows : nred, col_lim = RC ? nred : nrows;
     mask = 0u;                          // bit v: regs[v] is in range (applied at stage_store, so that nothing
                                         // consumes the loaded data -- and waits on it -- before the MFMA block)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const int idx = tid + v * 256;
+        const int idx = tid + v * NT;
         int r, c;                       // r: index along the tile's non-contiguous dim, c: float4 along the contiguous one
         if (RC) { c = idx & (BK / 4 - 1); r = idx / (BK / 4); }
+        else if (KSEQ) { c = tid & (ROWS / 4 - 1); r = NV * (tid / (ROWS / 4)) + v; }   // NV consecutive k per thread
         else { c = idx & (ROWS / 4 - 1); r = idx / (ROWS / 4); }
         const int grow = RC ? row0 + r : red0 + r;        // global row
         const int gcol = RC ? red0 + 4 * c : row0 + 4 * c;
@@ -150,9 +151,183 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const
 
 }
 
-template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF>
-__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x6") mainloop: the same fp32 GEMM computed on the bf16 matrix cores, which on
+// gfx950 run 16x the fp32-input MFMA rate.  Each fp32 operand is split exactly into three bf16
+// terms x = h + m + l (round-to-nearest at each level: |m| <= 2^-8 |x|, |l| <= 2^-16 |x|, and the
+// 24-bit significand is covered, so the split itself loses nothing).  The product a.b is summed
+// from the six term products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm), each EXACT in the fp32
+// accumulator of v_mfma_f32_32x32x16_bf16; the three dropped ones (ml, lm, ll) are <= 2^-23 |ab|
+// worst case and unbiased -- below one fp32 rounding of the product.  6 bf16 MFMAs of 32 cycles
+// replace 8 fp32 MFMAs of 64 per 32x32x16 block: 2.67x the MFMA-bound rate at fp32 accuracy
+// (tests/test_hip_ppo.py checks both paths against float64).
+//
+// LDS image per operand: 3 planes [physical row][32 bf16 + 16 B pad] (80-B rows: a 5-slot stride
+// keeps the 16-lane groups of ds_read_b128 on distinct 16-B slots).  Logical row r lives at
+// physical row (r&3)*(ROWS/4+4) + (r>>2): the operand whose reduction dimension is NOT contiguous
+// in memory arrives as float4s along the rows, and this places the four rows of one float4 in
+// four different bank phases while fragment reads (32 consecutive rows) stay conflict-free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define X6_ROWB 80
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (x0, x1) -> packed bf16 pairs of the three split terms
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(m << 16);
+    r1 -= __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(r0, r1);
+}
+template <int ROWS>
+__device__ __forceinline__ int x6_prow(int r) { return (r & 3) * (ROWS / 4 + 4) + (r >> 2); }
+template <int ROWS>
+constexpr int x6_plane_bytes() { return (ROWS + 16) * X6_ROWB; }
+
+template <bool RC, int ROWS, int NT>
+__device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, const float4 (&regs)[ROWS * BK / 4 / NT], unsigned mask) {
+    constexpr int NV = ROWS * BK / 4 / NT;
+    constexpr int PL = x6_plane_bytes<ROWS>();
+    const int tid = threadIdx.x;
+    if (RC) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int idx = tid + v * NT;
+            const int c = idx & (BK / 4 - 1), r = idx / (BK / 4);
+            const bool in = (mask >> v) & 1u;
+            const float x0 = in ? regs[v].x : 0.f, x1 = in ? regs[v].y : 0.f, x2 = in ? regs[v].z : 0.f, x3 = in ? regs[v].w : 0.f;
+            uint32_t h0, m0, l0, h1, m1, l1;
+            split2(x0, x1, h0, m0, l0);
+            split2(x2, x3, h1, m1, l1);
+            unsigned char *d = lds + x6_prow<ROWS>(r) * X6_ROWB + 8 * c;
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + PL) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2 *>(d + 2 * PL) = make_uint2(l0, l1);
+        }
+    } else {
+        // regs[v] = rows 4c..4c+3 at k = NV*kg + v (stage_load KSEQ mapping)
+        const int c = tid & (ROWS / 4 - 1), kg = tid / (ROWS / 4);
+        float e[4][NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool in = (mask >> v) & 1u;
+            e[0][v] = in ? regs[v].x : 0.f; e[1][v] = in ? regs[v].y : 0.f;
+            e[2][v] = in ? regs[v].z : 0.f; e[3][v] = in ? regs[v].w : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned char *d = lds + (q * (ROWS / 4 + 4) + c) * X6_ROWB + 2 * NV * kg;
+            if (NV == 4) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split2(e[q][0], e[q][1], h0, m0, l0);
+                split2(e[q][2 % NV], e[q][3 % NV], h1, m1, l1);
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(d + PL) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(d + 2 * PL) = make_uint2(l0, l1);
+            } else {
+                static_assert(NV == 4 || NV == 2, "tile/threads combination");
+                uint32_t h0, m0, l0;
+                split2(e[q][0], e[q][1 % NV], h0, m0, l0);
+                *reinterpret_cast<uint32_t *>(d) = h0;
+                *reinterpret_cast<uint32_t *>(d + PL) = m0;
+                *reinterpret_cast<uint32_t *>(d + 2 * PL) = l0;
+            }
+        }
+    }
+}
+
+template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC>
+__device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
+                                                 int M, int N, int k_begin, int k_end, unsigned char *__restrict__ lds, int wm, int wn, int li,
+                                                 int lk, f32x16 (&acc)[TM][TN]) {
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
+    constexpr int APL = x6_plane_bytes<BM>(), BPL = x6_plane_bytes<BN>();
+    constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;
+    // two register sets: the global loads of k-tile t+2 are issued before the MFMAs of tile t, and tile
+    // t+1 (already landed) is split and stored after them -- one full iteration to cover the L2/HBM latency
+    float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
+    unsigned ma0, mb0, ma1 = 0, mb1 = 0;
+    unsigned char *lds_b = lds + 3 * APL;
+    stage_load<A_RC, BM, VEC, true, NT>(A, lda, m0, k_begin, M, k_end, ra0, ma0);
+    stage_load<B_RC, BN, VEC, true, NT>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
+    if (k_begin + BK < k_end) {
+        stage_load<A_RC, BM, VEC, true, NT>(A, lda, m0, k_begin + BK, M, k_end, ra1, ma1);
+        stage_load<B_RC, BN, VEC, true, NT>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
+    }
+    stage_store_x6<A_RC, BM, NT>(lds, ra0, ma0);
+    stage_store_x6<B_RC, BN, NT>(lds_b, rb0, mb0);
+    __syncthreads();
+    // fragment of tile a, plane p, k-step s: base + a*8*X6_ROWB (32 logical rows = 8 physical) + p*PL + s*32
+    const unsigned char *fa = lds + x6_prow<BM>(wm + li) * X6_ROWB + 16 * lk;
+    const unsigned char *fb = lds_b + x6_prow<BN>(wn + li) * X6_ROWB + 16 * lk;
+
+    auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA], float4 (&yb)[NVB],
+                    unsigned &yma, unsigned &ymb) {
+        if (k0 + 2 * BK < k_end) {
+            stage_load<A_RC, BM, VEC, true, NT>(A, lda, m0, k0 + 2 * BK, M, k_end, ya, yma);
+            stage_load<B_RC, BN, VEC, true, NT>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
+        }
+        bf16x8 av[2][TM][3], bv[2][TN][3];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) av[0][a][p] = *reinterpret_cast<const bf16x8 *>(fa + a * 8 * X6_ROWB + p * APL);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bv[0][b][p] = *reinterpret_cast<const bf16x8 *>(fb + b * 8 * X6_ROWB + p * BPL);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            if (s + 1 < BK / 16) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        av[(s + 1) & 1][a][p] = *reinterpret_cast<const bf16x8 *>(fa + a * 8 * X6_ROWB + p * APL + (s + 1) * 32);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bv[(s + 1) & 1][b][p] = *reinterpret_cast<const bf16x8 *>(fb + b * 8 * X6_ROWB + p * BPL + (s + 1) * 32);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const bf16x8 *x = av[s & 1][a], *y = bv[s & 1][b];
+                    f32x16 c = acc[a][b];                 // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+        }
+        __syncthreads();                         // every wave is done reading before the tile is refilled
+        if (k0 + BK < k_end) {
+            stage_store_x6<A_RC, BM, NT>(lds, xa, xma);
+            stage_store_x6<B_RC, BN, NT>(lds_b, xb, xmb);
+        }
+        __syncthreads();
+    };
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+        body(k0, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
+        if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
+    }
+}
+
+template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2>
+__global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) : 1) k_gemm(GemmArgs g) {
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;       // WGM x WGN waves, each TM x TN tiles of 32x32
+    static_assert(X6 || (WGM == 2 && WGN == 2), "the fp32-input mainloop is written for 2x2 waves");
     const int z = blockIdx.z;
     const int M = g.M[z], N = g.N[z], K = g.K[z];
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
@@ -175,10 +350,12 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (((B_RC ? k_end : N) & 3) == 0) && (B_RC ? k_end : N) >= 4;
 
     constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
-    __shared__ float lds[(DBUF ? 2 : 1) * (AF + BF)];
+    constexpr int LDS_BYTES = X6 ? 3 * (x6_plane_bytes<BM>() + x6_plane_bytes<BN>()) : (DBUF ? 2 : 1) * (AF + BF) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    float *lds = reinterpret_cast<float *>(lds_raw);
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wm = (wave >> 1) * 32 * TM, wn = (wave & 1) * 32 * TN;
+    const int wm = (wave / WGN) * 32 * TM, wn = (wave % WGN) * 32 * TN;
     const int li = lane & 31, lk = lane >> 5;
 
     f32x16 acc[TM][TN];
@@ -189,8 +366,13 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (a_vec && b_vec) gemm_mainloop<A_RC, B_RC, TM, TN, true, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
-    else gemm_mainloop<A_RC, B_RC, TM, TN, false, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
+    if (X6) {
+        if (a_vec && b_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
+        else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
+    } else {
+        if (a_vec && b_vec) gemm_mainloop<A_RC, B_RC, TM, TN, true, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
+        else gemm_mainloop<A_RC, B_RC, TM, TN, false, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
+    }
 
     // ---- epilogue.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *__restrict__ C = g.C[z];
@@ -272,6 +454,9 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 
 static int g_gemm_dbuf = 0;   // single LDS buffer (34 KB, 4 workgroups/CU) measured 3-15 % faster than double buffering
 extern "C" void ppok_debug_set_dbuf(int v) { g_gemm_dbuf = v; }
+static int g_gemm_x6 = 1;     // split-bf16 mainloop (fp32 accuracy on the bf16 matrix cores); 0 = fp32-input MFMA
+static int g_gemm_w8 = 1;     // 128x128 tile on 8 waves (2x4, each 64x32) instead of 4 waves (2x2, each 64x64)
+extern "C" void ppok_debug_set_x6(int v) { g_gemm_x6 = v & 1; g_gemm_w8 = (v >> 1) & 1; }
 
 template <bool A_RC, bool B_RC, int EPI>
 static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
@@ -281,11 +466,14 @@ static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
     const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
     if (big_tiles * splits >= 192 && maxN > 64 && maxM > 64) {
         dim3 grid((unsigned)big_tiles, splits, nz);
-        if (g_gemm_dbuf) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2, true>), grid, dim3(256), 0, s, g);
+        if (g_gemm_x6 && g_gemm_w8) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 1, false, true, 2, 4>), grid, dim3(512), 0, s, g);
+        else if (g_gemm_x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2, false, true>), grid, dim3(256), 0, s, g);
+        else if (g_gemm_dbuf) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2, true>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 2, 2, false>), grid, dim3(256), 0, s, g);
     } else {
         dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), splits, nz);
-        hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, true>), grid, dim3(256), 0, s, g);
+        if (g_gemm_x6) hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, true>), grid, dim3(256), 0, s, g);
     }
 }
 extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) { launch_gemm<true, true, 0>(*g, nz, 1, s); }
