@@ -25,7 +25,9 @@ os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
+MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0     # bf16 MFMA dense peak (MI355X_MICROARCH.md); the split-bf16 GEMM issues 6 bf16 MFMAs per
+MFMA_X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32 product block, so its fp32-equivalent ceiling is 2500 / 6 = 416.7 TFLOP/s
 BYTES_PER_ENV_STEP = 4200.0    # flat ANYmal, fused-step algorithmic bytes
 
 
@@ -93,8 +95,11 @@ def time_iterations(runner, steps, warmup, world):
 
 
 def gemm_roofline(runner, hidden, reps=8):
-    """fp32-MFMA GEMM group of one minibatch (forward + backward of actor and critic), timed live
-    with HIP events on the launch stream; algorithmic FLOPs = 2 * MACs * rows * 3."""
+    """GEMM group of one minibatch (forward + backward of actor and critic: split-bf16 k_gemm launches
+    plus gather/loss), timed live with HIP events on the launch stream; algorithmic (fp32) FLOPs =
+    2 * MACs * rows * 3.  The kernels compute fp32-accurate products as 6 bf16 MFMAs
+    per 32x32x16 block, so the ceiling is the bf16 dense peak / 6; the fp32-input MFMA peak (what a
+    v_mfma_f32_32x32x2_f32 kernel is bounded by) is reported beside it."""
     ppo = runner.ppo
     R = ppo.T * ppo.N // ppo.cfg.num_mini_batches
     ppo._call("begin_update")
@@ -111,9 +116,11 @@ def gemm_roofline(runner, hidden, reps=8):
     flops = 2.0 * macs_per_sample(ppo.O, list(hidden), ppo.A) * R * 3.0
     n_launch = (len(hidden) + 1) * 3 - 1          # fwd + dW per layer, dX for all but the first (actor+critic batched on grid.z)
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_gemm<fp32 mfma_32x32x2> (ActorCritic fwd+bwd of one minibatch)",
-            "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-            "traffic": None, "flops_per_minibatch": flops, "ms_per_minibatch": round(ms, 4), "gemm_launches": n_launch}
+    return {"bound": "mfma", "kernel": "k_gemm<split-bf16 x6, mfma_f32_32x32x16_bf16> (ActorCritic fwd+bwd of one minibatch)",
+            "achieved": round(ach, 3), "peak": round(MFMA_X6_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(ach / MFMA_X6_PEAK_TF, 4),
+            "traffic": None, "flops_per_minibatch": flops, "ms_per_minibatch": round(ms, 4), "gemm_launches": n_launch,
+            "mfma_executed_tflops": round(6.0 * ach, 2), "bf16_mfma_peak": MFMA_BF16_PEAK_TF,
+            "fp32_input_mfma_peak": MFMA_F32_PEAK_TF, "frac_of_fp32_input_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4)}
 
 
 def env_roofline(env, reps=50):

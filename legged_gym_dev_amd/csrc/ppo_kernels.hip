@@ -21,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // EPI 2: C += acc via float atomics, reduction split over blockIdx.y   (weight gradient)
 #define BK 32
 
-template <bool RC, int ROWS, bool VEC, bool KSEQ = false, int NT = 256>
+template <bool RC, int ROWS, bool VEC, bool KSEQ = false, int NT = 256, bool FULL = false>
 __device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld, int row0, int red0, int nrows, int nred,
                                            float4 (&regs)[ROWS * BK / 4 / NT], unsigned &mask) {
     constexpr int NV = ROWS * BK / 4 / NT;
@@ -38,7 +38,10 @@ __device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld
         else { c = idx & (ROWS / 4 - 1); r = idx / (ROWS / 4); }
         const int grow = RC ? row0 + r : red0 + r;        // global row
         const int gcol = RC ? red0 + 4 * c : row0 + 4 * c;
-        if (VEC) {
+        if (FULL) {                     // tile entirely in range (workgroup-uniform): no clamps, no mask
+            regs[v] = *reinterpret_cast<const float4 *>(src + (size_t)grow * ld + gcol);
+            mask = ~0u;
+        } else if (VEC) {
             // branch-free: every lane loads 16 B from a clamped (always valid) address and zeroes it by
             // select when out of range -- a guarded load makes hipcc wait vmcnt(0) per element.
             // VEC implies col_lim % 4 == 0, so a float4 is entirely inside or entirely outside.
@@ -178,19 +181,19 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 }
 // (x0, x1) -> packed bf16 pairs of the three split terms
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));      // v_pk_add_f32: both remainders in one instruction
     h = cvt_pk_bf16(x0, x1);
-    float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = cvt_pk_bf16(r0, r1);
-    r0 -= __uint_as_float(m << 16);
-    r1 -= __uint_as_float(m & 0xffff0000u);
-    l = cvt_pk_bf16(r0, r1);
+    f32x2 r = f32x2{x0, x1} - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    m = cvt_pk_bf16(r.x, r.y);
+    r -= f32x2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    l = cvt_pk_bf16(r.x, r.y);
 }
 template <int ROWS>
 __device__ __forceinline__ int x6_prow(int r) { return (r & 3) * (ROWS / 4 + 4) + (r >> 2); }
 template <int ROWS>
 constexpr int x6_plane_bytes() { return (ROWS + 16) * X6_ROWB; }
 
-template <bool RC, int ROWS, int NT>
+template <bool RC, int ROWS, int NT, bool FULL = false>
 __device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, const float4 (&regs)[ROWS * BK / 4 / NT], unsigned mask) {
     constexpr int NV = ROWS * BK / 4 / NT;
     constexpr int PL = x6_plane_bytes<ROWS>();
@@ -200,7 +203,7 @@ __device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, 
         for (int v = 0; v < NV; ++v) {
             const int idx = tid + v * NT;
             const int c = idx & (BK / 4 - 1), r = idx / (BK / 4);
-            const bool in = (mask >> v) & 1u;
+            const bool in = FULL || ((mask >> v) & 1u);
             const float x0 = in ? regs[v].x : 0.f, x1 = in ? regs[v].y : 0.f, x2 = in ? regs[v].z : 0.f, x3 = in ? regs[v].w : 0.f;
             uint32_t h0, m0, l0, h1, m1, l1;
             split2(x0, x1, h0, m0, l0);
@@ -216,7 +219,7 @@ __device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, 
         float e[4][NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const bool in = (mask >> v) & 1u;
+            const bool in = FULL || ((mask >> v) & 1u);
             e[0][v] = in ? regs[v].x : 0.f; e[1][v] = in ? regs[v].y : 0.f;
             e[2][v] = in ? regs[v].z : 0.f; e[3][v] = in ? regs[v].w : 0.f;
         }
@@ -242,7 +245,7 @@ __device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, 
     }
 }
 
-template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC>
+template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false>
 __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
                                                  int M, int N, int k_begin, int k_end, unsigned char *__restrict__ lds, int wm, int wn, int li,
                                                  int lk, f32x16 (&acc)[TM][TN]) {
@@ -254,14 +257,14 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
     unsigned ma0, mb0, ma1 = 0, mb1 = 0;
     unsigned char *lds_b = lds + 3 * APL;
-    stage_load<A_RC, BM, VEC, true, NT>(A, lda, m0, k_begin, M, k_end, ra0, ma0);
-    stage_load<B_RC, BN, VEC, true, NT>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
+    stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin, M, k_end, ra0, ma0);
+    stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
     if (k_begin + BK < k_end) {
-        stage_load<A_RC, BM, VEC, true, NT>(A, lda, m0, k_begin + BK, M, k_end, ra1, ma1);
-        stage_load<B_RC, BN, VEC, true, NT>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
+        stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin + BK, M, k_end, ra1, ma1);
+        stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
     }
-    stage_store_x6<A_RC, BM, NT>(lds, ra0, ma0);
-    stage_store_x6<B_RC, BN, NT>(lds_b, rb0, mb0);
+    stage_store_x6<A_RC, BM, NT, FULL>(lds, ra0, ma0);
+    stage_store_x6<B_RC, BN, NT, FULL>(lds_b, rb0, mb0);
     __syncthreads();
     // fragment of tile a, plane p, k-step s: base + a*8*X6_ROWB (32 logical rows = 8 physical) + p*PL + s*32
     const unsigned char *fa = lds + x6_prow<BM>(wm + li) * X6_ROWB + 16 * lk;
@@ -270,8 +273,8 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA], float4 (&yb)[NVB],
                     unsigned &yma, unsigned &ymb) {
         if (k0 + 2 * BK < k_end) {
-            stage_load<A_RC, BM, VEC, true, NT>(A, lda, m0, k0 + 2 * BK, M, k_end, ya, yma);
-            stage_load<B_RC, BN, VEC, true, NT>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
+            stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k0 + 2 * BK, M, k_end, ya, yma);
+            stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
         }
         bf16x8 av[2][TM][3], bv[2][TN][3];
 #pragma unroll
@@ -313,8 +316,8 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
         }
         __syncthreads();                         // every wave is done reading before the tile is refilled
         if (k0 + BK < k_end) {
-            stage_store_x6<A_RC, BM, NT>(lds, xa, xma);
-            stage_store_x6<B_RC, BN, NT>(lds_b, xb, xmb);
+            stage_store_x6<A_RC, BM, NT, FULL>(lds, xa, xma);
+            stage_store_x6<B_RC, BN, NT, FULL>(lds_b, xb, xmb);
         }
         __syncthreads();
     };
@@ -367,7 +370,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     if (X6) {
-        if (a_vec && b_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
+        // whole tile in range in all three dimensions (workgroup-uniform): staging without clamps and masks
+        const bool full = a_vec && b_vec && m0 + BM <= M && n0 + BN <= N && ((k_end - k_begin) % BK) == 0;
+        if (full) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
+        else if (a_vec && b_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
         else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
     } else {
         if (a_vec && b_vec) gemm_mainloop<A_RC, B_RC, TM, TN, true, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
