@@ -105,6 +105,23 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
         h.n_leg_slots = cnt[0];
         for (int l = 1; l < L; ++l)
             if (cnt[l] != cnt[0]) { g_err = "legs differ in their number of collision spheres"; delete c; return -11; }
+        if (J > LG_LT_MAXJ || L > 8) { g_err = "kinematic tree beyond the per-leg table"; delete c; return -12; }
+        for (int l = 0; l < L; ++l) {
+            float *t = h.leg_tab[l];
+            for (int j = 0; j < J; ++j) {
+                const int d = l * J + j;
+                float *q = t + LG_LT_JOINT * j;
+                memcpy(q, model->R_pj[d], 36); memcpy(q + 9, model->p_pj[d], 12); memcpy(q + 12, model->axis[d], 12);
+                memcpy(q + 15, model->inertia[d + 1], 36); memcpy(q + 24, model->com[d + 1], 12);
+                q[27] = model->mass[d + 1]; q[28] = model->joint_damping[d]; q[29] = model->vel_limit[d];
+            }
+            for (int s = 0; s < h.n_leg_slots; ++s) {
+                memcpy(t + LG_LT_SLOTS + 4 * s, h.slot_center[s][l], 12);
+                t[LG_LT_SLOTS + 4 * s + 3] = h.slot_radius[s][l];
+            }
+            memcpy(t + LG_LT_BASE, h.base_center[l], 12);
+            t[LG_LT_BASE + 3] = h.base_radius[l];
+        }
     }
 
     lg_buffers &b = h.buf;

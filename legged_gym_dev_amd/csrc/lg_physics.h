@@ -156,10 +156,11 @@ __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
 template <int L, int J>
 __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
                                              float *qd, const float *tau, float friction, float dmass,
-                                             V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt) {
+                                             V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt,
+                                             const float *__restrict__ ltab) {
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
-    const int d0 = leg * J;
+    const float *__restrict__ lt = ltab + leg * LG_LT_STRIDE;       // this leg's constants (LDS)
     const M3 Rb = quat_to_mat(root + 3);
     const V3 xw = {root[0], root[1], root[2]};
     const V3 vb = mulT(Rb, V3{root[7], root[8], root[9]}), wb = mulT(Rb, V3{root[10], root[11], root[12]});
@@ -179,10 +180,10 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
         Sv vpar = vel0;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const int d = d0 + j;
-            M3 Rj = mul(Rpar, load3(m.R_pj[d]));
-            V3 ax = ld3(m.axis[d]);
-            V3 pj = ppar + mul(Rpar, ld3(m.p_pj[d]));
+            const float *jt = lt + LG_LT_JOINT * j;
+            M3 Rj = mul(Rpar, load3(jt));
+            V3 ax = ld3(jt + 12);
+            V3 pj = ppar + mul(Rpar, ld3(jt + 9));
             V3 axb = mul(Rj, ax);
             M3 Rlj = mul(Rj, rodrigues(ax, q[j]));
             S[j] = {axb, cross(pj, axb)};
@@ -208,15 +209,15 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
         for (int b = 0; b < 6; ++b) Ia_run.m[a][b] = 0.f;
 #pragma unroll
     for (int j = J - 1; j >= 0; --j) {
-        const int d = d0 + j;
+        const float *jt = lt + LG_LT_JOINT * j;
         M3 Rlj;
 #pragma unroll
         for (int e = 0; e < 9; ++e) Rlj.m[e / 3][e % 3] = LK(j, e);
         const V3 pj = {LK(j, 9), LK(j, 10), LK(j, 11)};
         const Sv velj = {{LK(j, 12), LK(j, 13), LK(j, 14)}, {LK(j, 15), LK(j, 16), LK(j, 17)}};
         const Sv cbj = {{LK(j, 18), LK(j, 19), LK(j, 20)}, {LK(j, 21), LK(j, 22), LK(j, 23)}};
-        M3 Ic = mulBT(mul(Rlj, load3(m.inertia[d + 1])), Rlj);
-        M6 IA = rigid_inertia(m.mass[d + 1], pj + mul(Rlj, ld3(m.com[d + 1])), Ic);
+        M3 Ic = mulBT(mul(Rlj, load3(jt + 15)), Rlj);
+        M6 IA = rigid_inertia(jt[27], pj + mul(Rlj, ld3(jt + 24)), Ic);
         Sv pA = crf(velj, mul6(IA, velj));
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -225,7 +226,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
         pA = pA + pa_run;
         U[j] = mul6(IA, S[j]);
         const float Dj = sdot(S[j], U[j]);
-        u[j] = (tau[j] - m.joint_damping[d] * qd[j]) - sdot(S[j], pA);
+        u[j] = (tau[j] - jt[28] * qd[j]) - sdot(S[j], pA);
         float Uv[6] = {U[j].w.x, U[j].w.y, U[j].w.z, U[j].v.x, U[j].v.y, U[j].v.z};
         const float invD = __frcp_rn(Dj);
         iD[j] = invD;
@@ -280,26 +281,30 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     const int nslots = P->n_leg_slots;
 #define CF(si, f) cst[((si) * LG_CT_NF + (f)) * 64 + lane]
     unsigned amask = 0u;                       // bit si: slot si of this lane is in contact
+    // sphere -> link table packed 4 bits per slot (wave-uniform scalar loads); the base slot maps to
+    // link -1 = "no joint between the contact and the base"
+    unsigned long long link_pk = 0ull;
+    for (int s = 0; s < nslots; ++s) link_pk |= (unsigned long long)(P->slot_link[s] & 15) << (4 * s);
+    // (1) detection over every slot: geometry only
     for (int s = 0; s <= nslots; ++s) {
         const bool is_base = (s == nslots);
         const int si = is_base ? LG_MAX_LEG_SLOTS : s;
         const bool exists = is_base ? (leg < P->n_base_spheres) : true;
-        int jl = 0;
         V3 cbk = {0.f, 0.f, 0.f}, Pc = {0.f, 0.f, 0.f}, nb = {0.f, 0.f, 1.f};
         float rad = 0.f, vtarget = 0.f;
         bool active = false;
         if (exists) {
             if (is_base) {
-                cbk = ld3(P->base_center[leg]);
-                rad = P->base_radius[leg];
+                cbk = ld3(lt + LG_LT_BASE);
+                rad = lt[LG_LT_BASE + 3];
             } else {
-                jl = P->slot_link[s];
+                const int jl = P->slot_link[s];
                 M3 Rk;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) Rk.m[e / 3][e % 3] = LK(jl, e);
                 const V3 pk = {LK(jl, 9), LK(jl, 10), LK(jl, 11)};
-                cbk = pk + mul(Rk, ld3(P->slot_center[s][leg]));
-                rad = P->slot_radius[s][leg];
+                cbk = pk + mul(Rk, ld3(lt + LG_LT_SLOTS + 4 * s));
+                rad = lt[LG_LT_SLOTS + 4 * s + 3];
             }
             V3 cw = xw + mul(Rb, cbk);
             Ground g = ground_at(P, cw.x, cw.y);
@@ -311,10 +316,21 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                 vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
             }
         }
-        CF(si, 16) = active ? 1.0f : 0.0f;
+        CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
+        CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
+        CF(si, 12) = vtarget;
         CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
-        if (!__any(active)) continue;                    // wave-uniform skip
+        CF(si, 16) = active ? 1.0f : 0.0f;
         if (active) amask |= 1u << si;
+    }
+    // (2) W per ACTIVE slot: every lane walks its own list of set bits, so the trip count is the largest
+    // number of simultaneous contacts of any lane of the wave, not the number of slots in contact
+    // anywhere in it.  Per-lane order stays ascending in si (the base slot last).
+    for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
+        const bool valid = rem != 0u;
+        const int si = valid ? __ffs(rem) - 1 : 0;
+        const int jl = (si == LG_MAX_LEG_SLOTS) ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
+        const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
         V3 t1, t2;
         tangents(nb, t1, t2);
         V3 dirs[3] = {nb, t1, t2};
@@ -323,59 +339,50 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
         for (int a = 0; a < 3; ++a) {
             Sv pAi = {-1.0f * cross(Pc, dirs[a]), -1.0f * dirs[a]};
             float ui[J];
-            if (!is_base) {
 #pragma unroll
-                for (int k = J - 1; k >= 0; --k) {
-                    if (k <= jl) {
-                        ui[k] = -sdot(S[k], pAi);
-                        pAi = pAi + (ui[k] * iD[k]) * U[k];
-                    } else ui[k] = 0.f;
-                }
+            for (int k = J - 1; k >= 0; --k) {
+                if (k <= jl) {
+                    ui[k] = -sdot(S[k], pAi);
+                    pAi = pAi + (ui[k] * iD[k]) * U[k];
+                } else ui[k] = 0.f;
             }
             Sv dv = -1.0f * mul6(I0inv, pAi);
-            if (!is_base) {
 #pragma unroll
-                for (int k = 0; k < J; ++k)
-                    if (k <= jl) {
-                        float dq = (ui[k] - sdot(U[k], dv)) * iD[k];
-                        dv = dv + dq * S[k];
-                    }
-            }
+            for (int k = 0; k < J; ++k)
+                if (k <= jl) {
+                    float dq = (ui[k] - sdot(U[k], dv)) * iD[k];
+                    dv = dv + dq * S[k];
+                }
             V3 dvP = dv.v + cross(dv.w, Pc);
 #pragma unroll
             for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
         }
-        CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
-        CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
-        CF(si, 6) = Wc[0][0] > 1e-9f ? __frcp_rn(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
-        CF(si, 9) = Wc[1][1] > 1e-9f ? __frcp_rn(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
-        CF(si, 11) = Wc[2][2] > 1e-9f ? __frcp_rn(Wc[2][2]) : 0.f;
-        CF(si, 12) = vtarget;
+        if (valid) {
+            CF(si, 6) = Wc[0][0] > 1e-9f ? __frcp_rn(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
+            CF(si, 9) = Wc[1][1] > 1e-9f ? __frcp_rn(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
+            CF(si, 11) = Wc[2][2] > 1e-9f ? __frcp_rn(Wc[2][2]) : 0.f;
+        }
     }
     const bool base_active = (amask >> LG_MAX_LEG_SLOTS) & 1u;
     const int n_base_active = (int)leg_sum<L>(base_active ? 1.0f : 0.0f);
     const int n_leg_active = __popc(amask & ((1u << LG_MAX_LEG_SLOTS) - 1u));
     const float rl = __frcp_rn((float)max(n_leg_active, 1)), rb = __frcp_rn((float)max(n_base_active, 1));
 
-    // ---- projected Jacobi sweeps (wave-uniform trip count; contact-free waves skip them)
+    // ---- projected Jacobi sweeps (wave-uniform trip counts; contact-free waves skip them)
     if (__any(amask != 0u)) {
         for (int it = 0; it < c.solver_iterations; ++it) {
             Sv fimp[J], fb = sv_zero();
 #pragma unroll
             for (int k = 0; k < J; ++k) fimp[k] = sv_zero();
-            for (int s = 0; s <= nslots; ++s) {
-                const bool is_base = (s == nslots);
-                const int si = is_base ? LG_MAX_LEG_SLOTS : s;
-                const bool active = (amask >> si) & 1u;
-                if (!__any(active)) continue;
-                const int jl = is_base ? 0 : P->slot_link[s];
+            for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
+                const bool active = rem != 0u;
+                const int si = active ? __ffs(rem) - 1 : 0;
+                const bool is_base = si == LG_MAX_LEG_SLOTS;
+                const int jl = is_base ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
                 Sv vl = velf0;
-                if (!is_base) {
-                    vl = velf[0];
 #pragma unroll
-                    for (int k = 1; k < J; ++k)
-                        if (jl == k) vl = velf[k];
-                }
+                for (int k = 0; k < J; ++k)
+                    if (jl == k) vl = velf[k];
                 if (active) {
                     const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
                     const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
@@ -396,11 +403,9 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                     CF(si, 13) = ln; CF(si, 14) = l1; CF(si, 15) = l2;
                     Sv f = {cross(Pc, dl), dl};
                     if (is_base) fb = fb + f;
-                    else {
 #pragma unroll
-                        for (int k = 0; k < J; ++k)
-                            if (jl == k) fimp[k] = fimp[k] + f;
-                    }
+                    for (int k = 0; k < J; ++k)
+                        if (jl == k) fimp[k] = fimp[k] + f;
                 }
             }
             float ui[J];
@@ -456,7 +461,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         float v = qdf[j];
-        float vl = m.vel_limit[d0 + j];
+        float vl = lt[LG_LT_JOINT * j + 29];
         if (vl > 0.0f) v = fminf(fmaxf(v, -vl), vl);
         qd[j] = v;
         q[j] += dt * v;

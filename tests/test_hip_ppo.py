@@ -175,3 +175,42 @@ def test_full_update_tracks_torch():
     assert abs(hip.learning_rate - algo.learning_rate) < 1e-9
     assert np.isfinite(float(vl)) and np.isfinite(float(sl))
     hip.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 48), (3001, 77, 45), (1024, 256, 512), (640, 12, 128), (777, 1, 129)])
+def test_split_bf16_gemm_is_fp32_accurate(mode, M, N, K):
+    """The split-bf16 (x6) mainloop against a float64 product, beside the exact fp32-input MFMA
+    mainloop on the same operands: its error may not exceed the fp32 path's beyond fp32 rounding of
+    the result (tolerance: max |err| <= 2 x fp32-MFMA error + 2^-22 x max |C|).  Modes: 0 = A.B^T (forward), 1 = A.B with the
+    ELU' epilogue (input gradient; aux = 1), 2 = A^T.B accumulated with split-K atomics (weight
+    gradient).  Ragged / tiny shapes take the masked staging path, the big ones the interior one."""
+    import ctypes
+    from legged_gym_dev_amd.lib import load
+    lib = load()
+    lib.ppok_debug_gemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + mode)
+    # mixed magnitudes: the split has to be exact whatever the exponent
+    scale = torch.exp2(torch.randint(-12, 12, (K,), device="cuda", generator=g).float())
+    A = torch.randn(M, K, device="cuda", generator=g) * scale if mode < 2 else torch.randn(K, M, device="cuda", generator=g)
+    B = torch.randn(N, K, device="cuda", generator=g) / scale if mode == 0 else torch.randn(K, N, device="cuda", generator=g)
+    if mode == 1:
+        B = B / scale[:, None]
+    Ad = A.double() if mode < 2 else A.double().t()
+    ref = Ad @ (B.double().t() if mode == 0 else B.double())
+    splits = 1 if mode < 2 else 3
+    err = {}
+    try:
+        for x6 in (0, 1, 3):
+            lib.ppok_debug_set_x6(ctypes.c_int(x6))
+            C = torch.ones(M, N, device="cuda") if mode < 2 else torch.zeros(M, N, device="cuda")
+            lib.ppok_debug_gemm(vp(A), vp(B), vp(C), M, N, K, mode, splits, st)
+            torch.cuda.synchronize()
+            assert torch.isfinite(C).all()
+            err[x6] = float((C.double() - ref).abs().max())
+    finally:
+        lib.ppok_debug_set_x6(ctypes.c_int(3))
+    bound = 2.0 * err[0] + 2.0 ** -22 * float(ref.abs().max())
+    assert err[1] <= bound and err[3] <= bound, err
