@@ -10,6 +10,7 @@ void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
 extern "C" void lgk_torques(const DevParams *P, int n, int lstm, hipStream_t s);
+extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, hipStream_t s);
 extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s);
 extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
@@ -214,11 +215,22 @@ int lg_reset_all(lg_ctx *c) {
     lgk_reset_all(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
     return chk_launch();
 }
+static int g_fused_substeps = 1;
+int lg_debug_set_fused(int v) { g_fused_substeps = v; return 0; }
+
 int lg_step(lg_ctx *c, const float *actions) {                  // legged_robot.py:80-104
-    int rc = lg_set_actions(c, actions);
-    for (int d = 0; d < c->h.cfg.decimation && !rc; ++d) {
-        rc = lg_compute_torques(c);
-        if (!rc) rc = lg_simulate(c);
+    int rc = -1;
+    if (g_fused_substeps) {                                     // one launch for clip + decimation x {torques, physics}
+        rc = lgk_substeps(c->d, actions, c->h.cfg.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg,
+                          c->h.cfg.use_actuator_net, c->stream);
+        if (!rc) rc = chk_launch();
+    }
+    if (rc == -1) {                                             // topology without a fused kernel: launch per substep
+        rc = lg_set_actions(c, actions);
+        for (int d = 0; d < c->h.cfg.decimation && !rc; ++d) {
+            rc = lg_compute_torques(c);
+            if (!rc) rc = lg_simulate(c);
+        }
     }
     if (!rc) rc = lg_post_physics_step(c);
     return rc;

@@ -106,25 +106,13 @@ __global__ void __launch_bounds__(256) k_torques(const DevParams *__restrict__ P
 __device__ __forceinline__ float fsigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-__global__ void __launch_bounds__(256) k_torques_lstm8(const DevParams *__restrict__ P) {
-    const lg_cfg &c = P->cfg;
-    const int A = c.num_actions, n = c.num_envs * A;
-    __shared__ float w[LG_LSTM_NW];
-    for (int i = threadIdx.x; i < LG_LSTM_NW; i += 256) w[i] = c.lstm_w[i];
-    __syncthreads();
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    int row = gid >> 3;
-    const int k = gid & 7;
-    const bool live = row < n;
-    if (!live) row = n - 1;
+// One actuator-net update of lane k (hidden unit k of both layers) of a row; w = the 972 weights in LDS.
+// Returns this lane's share of the output sum (reduced over the 8 lanes by the caller's butterflies).
+__device__ __forceinline__ float lstm8_update(const float *__restrict__ w, int k, float x0, float x1, float &h0, float &c0, float &h1,
+                                              float &c1) {
     const float *wih0 = w + 3, *whh0 = wih0 + 64, *bih0 = whh0 + 256, *bhh0 = bih0 + 32;
     const float *wih1 = bhh0 + 32, *whh1 = wih1 + 256, *bih1 = whh1 + 256, *bhh1 = bih1 + 32;
-    const float *lw = bhh1 + 32, *lb = lw + 8;
-    const int j = row % A;
-    const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[row];
-    const float x0 = (P->buf.actions[row] * c.action_scale + c.default_dof_pos[j] - st.x) * w[0], x1 = st.y * w[1];
-    const size_t ls = (size_t)n * 8, idx = (size_t)row * 8 + k;
-    float h0 = P->buf.lstm_h[idx], c0 = P->buf.lstm_c[idx], h1 = P->buf.lstm_h[ls + idx], c1 = P->buf.lstm_c[ls + idx];
+    const float *lw = bhh1 + 32;
     float g0[4], g1[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -152,9 +140,29 @@ __global__ void __launch_bounds__(256) k_torques_lstm8(const DevParams *__restri
     y += __shfl_xor(y, 1, 8);
     y += __shfl_xor(y, 2, 8);
     y += __shfl_xor(y, 4, 8);
+    return y;
+}
+
+__global__ void __launch_bounds__(256) k_torques_lstm8(const DevParams *__restrict__ P) {
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions, n = c.num_envs * A;
+    __shared__ float w[LG_LSTM_NW];
+    for (int i = threadIdx.x; i < LG_LSTM_NW; i += 256) w[i] = c.lstm_w[i];
+    __syncthreads();
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    int row = gid >> 3;
+    const int k = gid & 7;
+    const bool live = row < n;
+    if (!live) row = n - 1;
+    const int j = row % A;
+    const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[row];
+    const float x0 = (P->buf.actions[row] * c.action_scale + c.default_dof_pos[j] - st.x) * w[0], x1 = st.y * w[1];
+    const size_t ls = (size_t)n * 8, idx = (size_t)row * 8 + k;
+    float h0 = P->buf.lstm_h[idx], c0 = P->buf.lstm_c[idx], h1 = P->buf.lstm_h[ls + idx], c1 = P->buf.lstm_c[ls + idx];
+    const float y = lstm8_update(w, k, x0, x1, h0, c0, h1, c1);
     if (live) {
         P->buf.lstm_h[idx] = h0; P->buf.lstm_c[idx] = c0; P->buf.lstm_h[ls + idx] = h1; P->buf.lstm_c[ls + idx] = c1;
-        if (k == 0) P->buf.torques[row] = w[2] * (y + lb[0]);
+        if (k == 0) P->buf.torques[row] = w[2] * (y + w[LG_LSTM_NW - 1]);
     }
 }
 
@@ -217,6 +225,162 @@ __global__ void __launch_bounds__(64, 1) k_physics(const DevParams *__restrict__
     for (int j = 0; j < J; ++j)
         reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)env * A + d0 + j] = make_float2(q[j], qd[j]);
     if (leg == 0) {
+        float *wp = P->buf.root_states + (size_t)env * 13;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) wp[k] = root[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The control loop of LeggedRobot.step (LR:86-96) as ONE launch: clip the actions, then `decimation`
+// x {torque law, physics substep} with the robot state (root, q, qd), the actuator-net state (h, c of
+// both layers) and the model constants resident in registers / LDS for the whole loop -- read once and
+// written once per env step instead of once per substep, and 1 launch instead of 1 + 2 x decimation.
+// Block = 4 waves = 64/L environments.  Wave 0 runs the physics (lane = (env, leg), as k_physics).
+// All 256 lanes run the actuator net (8 lanes per (env, joint) row, 2J rounds per substep, the state of
+// each round in VGPRs); PD laws are evaluated by the physics lanes for their own joints.  q, qd and tau
+// cross between the two lane maps through LDS.  Results are bit-identical to the launch-per-substep
+// path (lg_set_actions / lg_compute_torques / lg_simulate), which stays as the operator-level API.
+template <int L, int J, bool LSTM>
+__global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in) {
+    constexpr int A = L * J, EPW = 64 / L, ROWS = EPW * A, NR = ROWS * 8 / 256;
+    const lg_cfg &c = P->cfg;
+    const lg_model &m = P->model;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = c.num_envs, B = c.num_bodies;
+    const int env0 = blockIdx.x * EPW;
+    const int nrow = min(ROWS, (N - env0) * A);              // live rows of this block
+    __shared__ float s_ct[(LG_MAX_LEG_SLOTS + 1) * LG_CT_NF * 64];
+    __shared__ float s_lk[J * LG_LK_NF * 64];
+    __shared__ float s_lt[L * LG_LT_STRIDE];
+    __shared__ float s_w[LSTM ? LG_LSTM_NW : 1];
+    __shared__ float s_act[ROWS], s_q[ROWS], s_qd[ROWS], s_tau[ROWS];
+    for (int t = tid; t < L * LG_LT_STRIDE; t += 256) s_lt[t] = (&P->leg_tab[0][0])[t];
+    if (LSTM)
+        for (int t = tid; t < LG_LSTM_NW; t += 256) s_w[t] = c.lstm_w[t];
+    const size_t row0 = (size_t)env0 * A;
+    for (int t = tid; t < ROWS; t += 256) {
+        const bool in = t < nrow;
+        const size_t r = row0 + (in ? t : 0);
+        const float a = fminf(fmaxf(a_in[r], -c.clip_actions), c.clip_actions);      // LR:86-87
+        if (in) P->buf.actions[r] = a;
+        const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[r];
+        s_act[t] = a; s_q[t] = st.x; s_qd[t] = st.y;
+    }
+    // actuator-net state of this thread's NR rows
+    float h0[NR], c0[NR], h1[NR], c1[NR];
+    const size_t ls = (size_t)N * A * 8;
+    if (LSTM) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int rl = r * 32 + (tid >> 3);
+            const size_t idx = (row0 + (rl < nrow ? rl : 0)) * 8 + (tid & 7);
+            h0[r] = P->buf.lstm_h[idx]; c0[r] = P->buf.lstm_c[idx]; h1[r] = P->buf.lstm_h[ls + idx]; c1[r] = P->buf.lstm_c[ls + idx];
+        }
+    }
+    // physics lanes (wave 0)
+    int env = env0 + lane / L;
+    const int leg = lane % L;
+    const bool live = env < N;
+    if (!live) env = N - 1;
+    const int rl0 = (lane / L) * A + leg * J;                // first row of this lane's joints in the block
+    float root[13], q[J], qd[J], tau[J];
+    float fr = 0.f, dm = 0.f;
+    if (wave == 0) {
+        const float *rp = P->buf.root_states + (size_t)env * 13;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) root[k] = rp[k];
+        fr = P->buf.friction[env]; dm = P->buf.base_mass_delta[env];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int t = live ? rl0 + j : 0;
+            q[j] = s_q[t]; qd[j] = s_qd[t];
+        }
+    }
+    const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
+    const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
+    float *cf = P->buf.contact_forces + (size_t)env * B * 3;
+    for (int sub = 0; sub < c.decimation; ++sub) {
+        // ---- torques
+        if (LSTM) {                                                          // AN:71-81
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int rl = r * 32 + (tid >> 3), k = tid & 7;
+                const int j = rl % A;
+                const float x0 = (s_act[rl] * c.action_scale + c.default_dof_pos[j] - s_q[rl]) * s_w[0], x1 = s_qd[rl] * s_w[1];
+                const float y = lstm8_update(s_w, k, x0, x1, h0[r], c0[r], h1[r], c1[r]);
+                if (k == 0) s_tau[rl] = s_w[2] * (y + s_w[LG_LSTM_NW - 1]);
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) tau[j] = s_tau[live ? rl0 + j : 0];
+            }
+        } else if (wave == 0) {                                              // LR:389-413
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int d = leg * J + j;
+                const float as = s_act[live ? rl0 + j : 0] * c.action_scale;
+                float t;
+                if (c.control_type == 0) t = c.p_gains[d] * (as + c.default_dof_pos[d] - q[j]) - c.d_gains[d] * qd[j];
+                else if (c.control_type == 1)
+                    t = c.p_gains[d] * (as - qd[j]) - c.d_gains[d] * (qd[j] - P->buf.last_dof_vel[(size_t)env * A + d]) / c.sim_dt;
+                else t = as;
+                tau[j] = clampf(t, -c.torque_limits[d], c.torque_limits[d]);
+            }
+        }
+        // ---- physics
+        if (wave == 0) {
+            const bool last = sub == c.decimation - 1;
+            if (last && live)
+                for (int b = 0; b < B; ++b) {
+                    const int dyn = m.body_dyn[b];
+                    if ((dyn < 0 ? 0 : dyn / J) == leg) { cf[3 * b] = 0.f; cf[3 * b + 1] = 0.f; cf[3 * b + 2] = 0.f; }
+                }
+            for (int s = 0; s < ns; ++s) {
+                V3 fslot[LG_MAX_LEG_SLOTS], fbase;
+                const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt);
+                if (fault && live && leg == 0) P->fault[env] = 1;
+                V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
+                if (last && live) {
+#pragma unroll
+                    for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k)
+                        if (k < P->n_leg_slots) {
+                            float *o = cf + 3 * P->slot_body[k][leg];
+                            o[0] += wgt * fslot[k].x; o[1] += wgt * fslot[k].y; o[2] += wgt * fslot[k].z;
+                        }
+                    if (leg == 0 && P->n_base_spheres > 0) {
+                        float *o = cf + 3 * P->base_body[0];
+                        o[0] += wgt * fb.x; o[1] += wgt * fb.y; o[2] += wgt * fb.z;
+                    }
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) { s_q[rl0 + j] = q[j]; s_qd[rl0 + j] = qd[j]; if (!LSTM) s_tau[rl0 + j] = tau[j]; }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write back (once per env step)
+    for (int t = tid; t < nrow; t += 256) {
+        reinterpret_cast<float2 *>(P->buf.dof_state)[row0 + t] = make_float2(s_q[t], s_qd[t]);
+        P->buf.torques[row0 + t] = s_tau[t];
+    }
+    if (LSTM) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int rl = r * 32 + (tid >> 3);
+            if (rl < nrow) {
+                const size_t idx = (row0 + rl) * 8 + (tid & 7);
+                P->buf.lstm_h[idx] = h0[r]; P->buf.lstm_c[idx] = c0[r]; P->buf.lstm_h[ls + idx] = h1[r]; P->buf.lstm_c[ls + idx] = c1[r];
+            }
+        }
+    }
+    if (wave == 0 && live && leg == 0) {
         float *wp = P->buf.root_states + (size_t)env * 13;
 #pragma unroll
         for (int k = 0; k < 13; ++k) wp[k] = root[k];
@@ -585,6 +749,14 @@ extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t 
     const int blocks = (N * L + 63) / 64;
     if (L == 4 && J == 3) hipLaunchKernelGGL((k_physics<4, 3>), dim3(blocks), dim3(64), 0, s, P);
     else if (L == 2 && J == 6) hipLaunchKernelGGL((k_physics<2, 6>), dim3(blocks), dim3(64), 0, s, P);
+    else return -1;
+    return 0;
+}
+extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, hipStream_t s) {
+    const int blocks = (N + 64 / L - 1) / (64 / L);
+    if (L == 4 && J == 3 && lstm) hipLaunchKernelGGL((k_substeps<4, 3, true>), dim3(blocks), dim3(256), 0, s, P, a_in);
+    else if (L == 4 && J == 3) hipLaunchKernelGGL((k_substeps<4, 3, false>), dim3(blocks), dim3(256), 0, s, P, a_in);
+    else if (L == 2 && J == 6 && !lstm) hipLaunchKernelGGL((k_substeps<2, 6, false>), dim3(blocks), dim3(256), 0, s, P, a_in);
     else return -1;
     return 0;
 }

@@ -175,3 +175,64 @@ def test_rollout_properties_at_baseline_size():
             env.close()
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_pd_V", "anymal_c_rough", "cassie"])
+def test_fused_control_loop_equals_launch_per_substep(name):
+    """lg_step's single-launch control loop (k_substeps: clip + decimation x {torque law, physics} with the
+    state resident on chip) against the operator-level sequence lg_set_actions / lg_compute_torques /
+    lg_simulate / lg_post_physics_step on a second context with the same seed (133 envs: the last block of
+    each kernel is ragged).  Same source, two kernels: hipcc contracts multiply-adds differently in each, so
+    fp32 buffers agree to rounding (rtol = atol = 2e-4 on >= 99.8 % of the elements after decimation substeps of contact dynamics, the
+    state is re-glued every policy step), clipped actions and masks bit-exactly."""
+    z, meta = harness.load_fixture(name)
+    n = 133
+    cfg = harness.make_cfg(name)
+    cfg.env.num_envs = n
+    meta = dict(meta, num_envs=n)
+    from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+    from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+    cm = compile_model(resolve_model("", meta["robot"]))
+    terrain = harness.FixtureTerrain(z, meta, cfg) if "const_height_samples" in z.files else None
+    hs = z["const_height_samples"] if terrain else None
+
+    def mk():
+        return harness.HipHandle(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), terrain=terrain, seed=7), hs)
+    a, b = mk(), mk()
+    try:
+        rng = np.random.default_rng(9)
+        A = meta["num_dofs"]
+        for e in (a, b):
+            e.set_step_counter(0)
+            e.inject(0)
+            e.call("reset_all")
+        dec = int(cfg.control.decimation)
+        if meta["custom_origins"]:
+            for e in (a, b):
+                e.set("env_origins", z["const_env_origins_init"][np.arange(n) % 64])
+                e.set("terrain_levels", z["const_terrain_levels_init"][np.arange(n) % 64])
+                e.set("terrain_types", z["const_terrain_types"][np.arange(n) % 64])
+                e.call("reset_all")
+        for t in range(6):
+            act = (rng.uniform(-3, 3, (n, A)) * (200.0 if t == 5 else 1.0)).astype(np.float32)   # the last step exercises the action clip
+            a.step(act)                                            # fused
+            b.set_actions(act)
+            for _ in range(dec):
+                b.call("compute_torques")
+                b.call("simulate")
+            b.call("post_physics_step")
+            for key in ("actions", "reset", "time_out", "episode_length"):
+                np.testing.assert_array_equal(a.get(key), b.get(key), err_msg=f"step {t} {key}")
+            for key in ("torques", "dof_state", "root_states", "obs", "rew", "lstm_h", "lstm_c", "episode_sums", "feet_air_time"):
+                x, y = a.get(key).astype(np.float64), b.get(key).astype(np.float64)
+                bad = np.abs(x - y) > 2e-4 + 2e-4 * np.abs(y)
+                # contact dynamics amplify rounding: a stray element may exceed the band, never by much
+                assert bad.mean() <= 2e-3 and np.abs(x - y).max() <= 5e-2 * max(1.0, np.abs(y).max()), f"step {t} {key}: {bad.sum()} of {bad.size}"
+            fa, fb = a.get("contact_forces"), b.get("contact_forces")
+            np.testing.assert_allclose(fa, fb, rtol=2e-3, atol=2e-3 * max(1.0, float(np.abs(fb).max())), err_msg=f"step {t} contact_forces")
+            for key in ("root_states", "dof_state", "lstm_h", "lstm_c", "last_dof_vel", "last_root_vel", "feet_air_time",
+                        "episode_sums", "last_actions", "commands"):
+                b.set(key, a.get(key))
+    finally:
+        a.close()
+        b.close()
