@@ -19,7 +19,7 @@ void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s);
 void ppok_adv_normalize(const PpoDev *P, hipStream_t s);
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s);
 void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s);
-void ppok_step(const PpoDev *P, hipStream_t s);
+void ppok_step(const PpoDev *P, int par, hipStream_t s);
 int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
                     int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c, hipStream_t s);
 }
@@ -40,6 +40,7 @@ struct lg_ppo {
     hipStream_t side;                        // weight-gradient GEMMs run here, overlapping the input-gradient chain
     hipEvent_t ev_dz, ev_side;
     int overlap;
+    int grads_dirty;                         // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
     int step, inject;
     int64_t act_count, update_count;
     int Mmax;
@@ -309,6 +310,7 @@ int lg_ppo_begin_update(lg_ppo *p) {
     (void)hipMemsetAsync(p->dev.stats + 2, 0, 2 * sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.stats + 5, 0, sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.loss_acc, 0, 4 * sizeof(float), p->stream);
+    p->grads_dirty = 1;                      // first backward of this update clears the gradient buffer
     return 0;
 }
 
@@ -316,7 +318,9 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     (void)epoch;
     PpoDev &d = p->dev;
     const int R = d.mb_rows;
-    (void)hipMemsetAsync(d.grads, 0, (size_t)(d.num_params + 2) * sizeof(float), p->stream);
+    // k_opt_adam leaves the gradient buffer zeroed; only a backward pass that was never stepped needs a clear
+    if (p->grads_dirty) (void)hipMemsetAsync(d.grads, 0, (size_t)(d.num_params + 2) * sizeof(float), p->stream);
+    p->grads_dirty = 1;
     ppok_gather(&d, mb, p->stream);
     Net &na = p->net[0], &nc = p->net[1];
     const int nl = na.nl, H3 = na.dims[nl - 1];
@@ -335,7 +339,8 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
 }
 
 int lg_ppo_minibatch_step(lg_ppo *p) {
-    ppok_step(&p->dev, p->stream);
+    ppok_step(&p->dev, (int)(p->update_count & 1), p->stream);
+    p->grads_dirty = 0;
     p->update_count++;
     return launch_ok();
 }

@@ -930,22 +930,27 @@ __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__res
 }
 
 // KL-adaptive learning rate (rsl_rl PPO.update) + reset of the norm accumulator
-__global__ void k_pre_step(PpoDev P) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float kl = P.grads[P.num_params] / ((float)P.mb_rows * (float)P.world);
-    float lr = P.stats[0];
-    if (P.adaptive) {
-        if (kl > P.desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
-        else if (kl < P.desired_kl / 2.0f && kl > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+// Optimiser step in two launches.  k_opt_prepare: squared gradient norm (block partials -> atomics into
+// loss_acc[2 + par]) and, on one lane, the KL-adaptive learning rate, the loss statistics and the Adam step
+// count.  k_opt_adam: clip_grad_norm_(max_norm) + torch.optim.Adam step (betas 0.9/0.999, eps 1e-8), then
+// zeroes what it consumed -- the gradient buffer (+ KL tail) for the next minibatch and the OTHER norm slot
+// (par alternates per step, so no block can still be reading the slot that is cleared).
+__global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float kl = P.grads[P.num_params] / ((float)P.mb_rows * (float)P.world);
+        float lr = P.stats[0];
+        if (P.adaptive) {
+            if (kl > P.desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+            else if (kl < P.desired_kl / 2.0f && kl > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+        }
+        P.stats[0] = lr;
+        P.stats[1] = kl;
+        P.stats[2] += P.loss_acc[0] / (float)P.mb_rows;
+        P.stats[3] += P.loss_acc[1] / (float)P.mb_rows;
+        P.stats[4] += 1.0f;                                  // Adam step count t (k_opt_adam reads the new value)
+        P.stats[5] += 1.0f;
+        P.loss_acc[0] = 0.f; P.loss_acc[1] = 0.f;
     }
-    P.stats[0] = lr;
-    P.stats[1] = kl;
-    P.stats[2] += P.loss_acc[0] / (float)P.mb_rows;
-    P.stats[3] += P.loss_acc[1] / (float)P.mb_rows;
-    P.stats[5] += 1.0f;
-    P.loss_acc[0] = 0.f; P.loss_acc[1] = 0.f; P.loss_acc[2] = 0.f;
-}
-__global__ void __launch_bounds__(256) k_grad_norm(PpoDev P) {
     float s = 0.f;
     const float inv_world = 1.0f / (float)P.world;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)gridDim.x * blockDim.x) {
@@ -959,13 +964,12 @@ __global__ void __launch_bounds__(256) k_grad_norm(PpoDev P) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(&P.loss_acc[2], red[0]);
+    if (threadIdx.x == 0) atomicAdd(&P.loss_acc[2 + par], red[0]);
 }
-// clip_grad_norm_(max_norm) + torch.optim.Adam step (betas 0.9/0.999, eps 1e-8)
-__global__ void k_adam(PpoDev P) {
-    const float total = sqrtf(P.loss_acc[2]);
+__global__ void __launch_bounds__(256) k_opt_adam(PpoDev P, int par) {
+    const float total = sqrtf(P.loss_acc[2 + par]);
     const float coef = fminf(P.max_grad_norm / (total + 1e-6f), 1.0f);
-    const float lr = P.stats[0], t = P.stats[4] + 1.0f;
+    const float lr = P.stats[0], t = P.stats[4];
     const float bc1 = 1.0f - powf(0.9f, t), bc2 = 1.0f - powf(0.999f, t);
     const float inv_world = 1.0f / (float)P.world;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)gridDim.x * blockDim.x) {
@@ -975,9 +979,13 @@ __global__ void k_adam(PpoDev P) {
         P.adam_m[k] = m;
         P.adam_v[k] = v;
         P.params[k] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+        P.grads[k] = 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.grads[P.num_params] = 0.f; P.grads[P.num_params + 1] = 0.f;
+        P.loss_acc[2 + (par ^ 1)] = 0.f;
     }
 }
-__global__ void k_adam_tick(PpoDev P) { if (threadIdx.x == 0 && blockIdx.x == 0) P.stats[4] += 1.0f; }
 
 extern "C" {
 void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
@@ -1011,11 +1019,9 @@ int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, f
 void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s) {
     hipLaunchKernelGGL(k_loss, dim3((P->mb_rows + 255) / 256), dim3(256), 0, s, *P, mu, v, dmu, dval);
 }
-void ppok_step(const PpoDev *P, hipStream_t s) {
-    hipLaunchKernelGGL(k_pre_step, dim3(1), dim3(64), 0, s, *P);
-    hipLaunchKernelGGL(k_grad_norm, dim3(128), dim3(256), 0, s, *P);
-    hipLaunchKernelGGL(k_adam, dim3(256), dim3(256), 0, s, *P);
-    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, *P);
+void ppok_step(const PpoDev *P, int par, hipStream_t s) {
+    hipLaunchKernelGGL(k_opt_prepare, dim3(128), dim3(256), 0, s, *P, par);
+    hipLaunchKernelGGL(k_opt_adam, dim3(256), dim3(256), 0, s, *P, par);
 }
 }
 
