@@ -116,11 +116,49 @@ def gemm_roofline(runner, hidden, reps=8):
     flops = 2.0 * macs_per_sample(ppo.O, list(hidden), ppo.A) * R * 3.0
     n_launch = (len(hidden) + 1) * 3 - 1          # fwd + dW per layer, dX for all but the first (actor+critic batched on grid.z)
     ach = flops / (ms * 1e-3) / 1e12
+    traffic = None                                  # HBM bytes per minibatch group from the committed PMC passes
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        if pm.get("policy_hidden") == list(hidden):
+            traffic = pm["gemm_group_bytes_per_minibatch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    big = single_gemm_roofline(R, hidden)
     return {"bound": "mfma", "kernel": "k_gemm<split-bf16 x6, mfma_f32_32x32x16_bf16> (ActorCritic fwd+bwd of one minibatch)",
             "achieved": round(ach, 3), "peak": round(MFMA_X6_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(ach / MFMA_X6_PEAK_TF, 4),
-            "traffic": None, "flops_per_minibatch": flops, "ms_per_minibatch": round(ms, 4), "gemm_launches": n_launch,
-            "mfma_executed_tflops": round(6.0 * ach, 2), "bf16_mfma_peak": MFMA_BF16_PEAK_TF,
+            "traffic": traffic, "flops_per_minibatch": flops, "ms_per_minibatch": round(ms, 4), "gemm_launches": n_launch,
+            "largest_launch": big, "mfma_executed_tflops": round(6.0 * ach, 2), "bf16_mfma_peak": MFMA_BF16_PEAK_TF,
             "fp32_input_mfma_peak": MFMA_F32_PEAK_TF, "frac_of_fp32_input_mfma_peak": round(ach / MFMA_F32_PEAK_TF, 4)}
+
+
+def single_gemm_roofline(rows, hidden, reps=20):
+    """The largest single GEMM launch of the update (forward of the widest hidden layer, one net), alone,
+    through the debug entry of the same kernel: flops of that launch / its duration (HIP events)."""
+    import ctypes
+    from legged_gym_dev_amd.lib import load
+    lib = load()
+    lib.ppok_debug_gemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    dims = list(hidden)
+    l = max(range(len(dims) - 1), key=lambda i: dims[i] * dims[i + 1]) if len(dims) > 1 else 0
+    K, N = (dims[l], dims[l + 1]) if len(dims) > 1 else (48, dims[0])
+    A = torch.randn(rows, K, device="cuda")
+    B = torch.randn(N, K, device="cuda")
+    C = torch.empty(rows, N, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: lib.ppok_debug_gemm(ctypes.c_void_p(A.data_ptr()), ctypes.c_void_p(B.data_ptr()), ctypes.c_void_p(C.data_ptr()),
+                                       rows, N, K, 0, 1, st)
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    tf = 2.0 * rows * N * K / (us * 1e-6) / 1e12
+    return {"shape_MNK": [rows, N, K], "us": round(us, 2), "achieved": round(tf, 2), "frac": round(tf / MFMA_X6_PEAK_TF, 4)}
 
 
 def env_roofline(env, reps=50):
@@ -135,8 +173,14 @@ def env_roofline(env, reps=50):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     gbs = BYTES_PER_ENV_STEP * env.num_envs / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "lg_step (4 x {torque, physics} + post-step)", "achieved": round(gbs, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)["env_step_bytes_per_call"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"bound": "hbm", "kernel": "lg_step (k_substeps: clip + 4 x {actuator net, physics} in one launch; k_post_step)", "achieved": round(gbs, 2),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
             "us_per_env_step_call": round(ms * 1e3, 2)}
 
 
@@ -191,6 +235,7 @@ def main():
     ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--hidden", type=str, default="512,256,128")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_alt", action="store_true", help="skip the [128,64,32] pass (profiling runs)")
     args = ap.parse_args()
     hidden = [int(v) for v in args.hidden.split(",")]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,7 +271,7 @@ def main():
     if rank == 0 and world == 1:
         out["roofline"] = gemm_roofline(runner, hidden)
         out["roofline_env_step"] = env_roofline(env)
-        if tuple(hidden) != (128, 64, 32):
+        if tuple(hidden) != (128, 64, 32) and not args.no_alt:
             env.close()
             runner.ppo.close()
             env2, runner2 = make_runner(args.num_envs, [128, 64, 32], device, rank, world)
