@@ -166,14 +166,24 @@ class HipPPO:
             self.param_views[k].copy_(v.to(self.device))
 
     def optimizer_state_dict(self):
-        return {"adam_m": self.t["adam_m"][: self.num_params].clone(), "adam_v": self.t["adam_v"][: self.num_params].clone(),
-                "step": float(self.t["stats"][4]), "lr": float(self.t["stats"][0])}
+        """torch.optim.Adam.state_dict() layout over ActorCritic.parameters() order (rl/checkpoint.py)."""
+        from .checkpoint import adam_state_to_torch
+        names = list(self.param_views.keys())          # flat-buffer order == parameters() order
+        shapes = {k: tuple(v.shape) for k, v in self.param_views.items()}
+        return adam_state_to_torch(names, shapes, self.t["adam_m"][: self.num_params], self.t["adam_v"][: self.num_params],
+                                   float(self.t["stats"][4]), float(self.t["stats"][0]))
 
     def load_optimizer_state_dict(self, sd):
-        self.t["adam_m"][: self.num_params].copy_(sd["adam_m"].to(self.device))
-        self.t["adam_v"][: self.num_params].copy_(sd["adam_v"].to(self.device))
-        self.t["stats"][4] = float(sd["step"])
-        self.t["stats"][0] = float(sd["lr"])
+        from .checkpoint import adam_state_from_torch
+        names = list(self.param_views.keys())
+        shapes = {k: tuple(v.shape) for k, v in self.param_views.items()}
+        m, v, step, lr = adam_state_from_torch(sd, names, shapes)
+        if m.numel() != self.num_params:
+            raise ValueError(f"optimizer state holds {m.numel()} values, the policy has {self.num_params}")
+        self.t["adam_m"][: self.num_params].copy_(m.to(self.device))
+        self.t["adam_v"][: self.num_params].copy_(v.to(self.device))
+        self.t["stats"][4] = step
+        self.t["stats"][0] = lr
 
     def close(self):
         if getattr(self, "ctx", None):

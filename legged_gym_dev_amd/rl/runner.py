@@ -165,15 +165,15 @@ class OnPolicyRunner:
     # ------------------------------------------------------------------ checkpoints
     def save(self, path, infos=None):
         os.makedirs(os.path.dirname(path), exist_ok=True)
+        # rsl_rl OnPolicyRunner.save layout; the optimiser entry is torch.optim.Adam's own state_dict
         torch.save({"model_state_dict": {k: v.cpu() for k, v in self.ppo.state_dict().items()},
-                    "optimizer_state_dict": {k: (v.cpu() if torch.is_tensor(v) else v)
-                                             for k, v in self.ppo.optimizer_state_dict().items()},
+                    "optimizer_state_dict": self.ppo.optimizer_state_dict(),
                     "iter": self.current_learning_iteration, "infos": infos}, path)
 
     def load(self, path, load_optimizer=True):
         d = torch.load(path, map_location="cpu", weights_only=True)
         self.ppo.load_state_dict(d["model_state_dict"])
-        if load_optimizer and "adam_m" in d.get("optimizer_state_dict", {}):
+        if load_optimizer and d.get("optimizer_state_dict"):
             self.ppo.load_optimizer_state_dict(d["optimizer_state_dict"])
         self.current_learning_iteration = d["iter"]
         return d.get("infos")

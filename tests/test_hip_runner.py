@@ -1,0 +1,105 @@
+"""GPU: the training / evaluation drivers on top of the C-ABI -- OnPolicyRunner.learn with checkpoints in
+rsl_rl's file layout, resume through task_registry (the path scripts/play.py takes), TorchScript export of
+the trained actor against lg_ppo_act_inference, and the play loop itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(task, n, extra=()):
+    from legged_gym_dev_amd.utils import get_args
+    a = get_args(["--task", task, "--num_envs", str(n), "--headless", *extra])
+    a.sim_device = a.rl_device = "cuda:0"
+    return a
+
+
+def test_learn_save_resume_export_play(tmp_path, monkeypatch):
+    import legged_gym_dev_amd
+    from legged_gym_dev_amd.envs import task_registry
+    from legged_gym_dev_amd.rl import checkpoint as ck
+    monkeypatch.setattr(legged_gym_dev_amd, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    import legged_gym_dev_amd.utils  # noqa: F401
+    monkeypatch.setattr(sys.modules["legged_gym_dev_amd.utils.task_registry"], "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    args = _args("anymal_c_flat", 64, ("--max_iterations", "3"))
+    env, env_cfg = task_registry.make_env(name=args.task, args=args)
+    env_cfg2, train_cfg = task_registry.get_cfgs(args.task)
+    train_cfg.runner.save_interval = 2
+    train_cfg.policy.actor_hidden_dims = [64, 32]
+    train_cfg.policy.critic_hidden_dims = [64, 32]
+    log_root = os.path.join(str(tmp_path), "logs", train_cfg.runner.experiment_name)
+    runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, train_cfg=train_cfg, log_root=log_root)
+    runner.learn(num_learning_iterations=3, init_at_random_ep_len=True)
+    files = sorted(os.listdir(runner.log_dir))
+    assert "model_0.pt" in files and "model_2.pt" in files and "model_3.pt" in files, files
+    d = torch.load(os.path.join(runner.log_dir, "model_3.pt"), map_location="cpu", weights_only=True)
+    assert set(d) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"} and d["iter"] == 3
+    assert list(d["model_state_dict"])[:3] == ["std", "actor.0.weight", "actor.0.bias"]
+    # the reference side can consume it: ActorCritic.load_state_dict + torch Adam.load_state_dict
+    from oracle import ppo_torch
+    ac = ppo_torch.ActorCritic(48, 48, 12, [64, 32], [64, 32], "elu", 1.0)
+    ac.load_state_dict(d["model_state_dict"])
+    torch.optim.Adam(ac.parameters()).load_state_dict(d["optimizer_state_dict"])
+    want_sd = {k: v.cpu().clone() for k, v in runner.ppo.state_dict().items()}
+    want_opt = runner.ppo.optimizer_state_dict()
+    obs = env.get_observations().clone()
+    mean_hip = runner.alg.actor_critic.actor(obs).cpu()
+    # TorchScript export == HIP inference (fp32 MFMA vs torch CPU: rtol 1e-4)
+    path = ck.export_policy_as_jit(runner.alg.actor_critic, str(tmp_path / "exported"))
+    mod = torch.jit.load(path)
+    np.testing.assert_allclose(mod(obs.cpu()).detach().numpy(), mean_hip.numpy(), rtol=1e-4, atol=1e-5)
+    env.close(); runner.ppo.close()
+    # resume the way play.py does
+    args2 = _args("anymal_c_flat", 8)
+    env_cfg, train_cfg = task_registry.get_cfgs(args2.task)
+    env_cfg.env.num_envs = 8
+    env2, _ = task_registry.make_env(name=args2.task, args=args2, env_cfg=env_cfg)
+    train_cfg.runner.resume = True
+    train_cfg.policy.actor_hidden_dims = [64, 32]
+    train_cfg.policy.critic_hidden_dims = [64, 32]
+    runner2, _ = task_registry.make_alg_runner(env=env2, name=args2.task, args=args2, train_cfg=train_cfg, log_root=log_root)
+    for k, v in runner2.ppo.state_dict().items():
+        assert torch.equal(v.cpu(), want_sd[k]), k
+    got_opt = runner2.ppo.optimizer_state_dict()
+    assert got_opt["param_groups"][0]["lr"] == want_opt["param_groups"][0]["lr"]
+    for i in want_opt["state"]:
+        assert torch.equal(got_opt["state"][i]["exp_avg_sq"], want_opt["state"][i]["exp_avg_sq"])
+        assert float(got_opt["state"][i]["step"]) == float(want_opt["state"][i]["step"]) == 60.0     # 3 iterations x 20 steps
+    assert runner2.current_learning_iteration == 3
+    policy = runner2.get_inference_policy(device=env2.device)
+    o = env2.get_observations()
+    for _ in range(5):
+        o, _, r, dn, info = env2.step(policy(o.detach()))
+    assert torch.isfinite(o).all() and torch.isfinite(r).all()
+    env2.close(); runner2.ppo.close()
+
+
+def test_play_script_runs(tmp_path, monkeypatch):
+    import legged_gym_dev_amd
+    from legged_gym_dev_amd.envs import task_registry
+    monkeypatch.setattr(legged_gym_dev_amd, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    monkeypatch.setattr(sys.modules["legged_gym_dev_amd.utils.task_registry"], "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    args = _args("anymal_c_flat", 16)
+    env, _ = task_registry.make_env(name=args.task, args=args)
+    _, shared = task_registry.get_cfgs(args.task)       # registered cfg objects are shared and mutated in place (as in the reference)
+    shared.runner.resume = False
+    shared.policy.actor_hidden_dims = [128, 64, 32]
+    shared.policy.critic_hidden_dims = [128, 64, 32]
+    runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args)
+    runner.learn(num_learning_iterations=1)
+    env.close(); runner.ppo.close()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "legged_gym_dev_amd", "scripts"))
+    import importlib
+    play = importlib.import_module("play")
+    monkeypatch.setattr(play, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    rec = play.play(_args("anymal_c_flat", 1), num_steps=120, out_mat=str(tmp_path / "play_data.mat"))
+    assert rec["pos"].shape == (120, 3) and np.isfinite(rec["torque"]).all() and np.abs(rec["action"]).sum() > 0
+    import scipy.io
+    m = scipy.io.loadmat(str(tmp_path / "play_data.mat"))
+    assert set(("cmd", "action", "pos", "quat", "dof", "vel", "omega", "ddof", "torque")) <= set(m)
+    assert os.path.exists(tmp_path / "logs" / train_cfg.runner.experiment_name / "exported" / "policies" / "policy_1.pt")
