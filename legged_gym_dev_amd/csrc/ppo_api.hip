@@ -10,7 +10,8 @@ void lg_set_error(const std::string &s);
 
 extern "C" {
 void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s);
-void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s);
+void ppok_gemm_dx(const GemmArgs *g, int nz, const int *ldb_planes, hipStream_t s);
+void ppok_sync_planes(const PpoDev *P, hipStream_t s);
 void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s);
 void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
                      int64_t cnt, int inject, hipStream_t s);
@@ -28,6 +29,7 @@ struct Net {
     int nl;                                  // linear layers (hidden + head)
     int dims[LG_PPO_MAX_LAYERS + 1];         // dims[0] = input, dims[nl] = output
     int64_t w_off[LG_PPO_MAX_LAYERS], b_off[LG_PPO_MAX_LAYERS];
+    int64_t pl_off[LG_PPO_MAX_LAYERS];       // offset of this layer's weight matrix inside a bf16 plane (multiple of 8)
     float *act[LG_PPO_MAX_LAYERS + 1];       // act[l], l >= 1: output of layer l-1 (workspace, Mmax rows)
     float *dz[LG_PPO_MAX_LAYERS + 1];        // gradient wrt act[l] pre-activation
 };
@@ -68,7 +70,7 @@ static int launch_ok() {
 }
 
 // forward of the selected nets on M rows.  in[z] = input of net z.  mask bit z selects the net.
-static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask, int skip_head = 0) {
+static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask, int skip_head = 0, bool planes = false) {
     const float *in[2] = {in0, in1};
     int sel[2], nz = 0;
     for (int z = 0; z < 2; ++z) if (mask & (1 << z)) sel[nz++] = z;
@@ -81,11 +83,13 @@ static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int ma
             g.A[k] = l == 0 ? in[sel[k]] : n.act[l];
             g.B[k] = p->dev.params + n.w_off[l];
             g.bias[k] = p->dev.params + n.b_off[l];
+            g.Bpl[k] = planes ? p->dev.wpl + n.pl_off[l] : nullptr;      // valid only inside an update (lg_ppo_begin_update syncs them)
             g.C[k] = n.act[l + 1];
             g.M[k] = M; g.N[k] = n.dims[l + 1]; g.K[k] = n.dims[l];
             g.lda[k] = n.dims[l]; g.ldb[k] = n.dims[l]; g.ldc[k] = n.dims[l + 1];
         }
         g.elu = l < nl - 1;
+        g.pl_stride = p->dev.pl_stride;
         ppok_gemm_fwd(&g, nz, p->stream);
     }
 }
@@ -123,6 +127,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         }
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * ELU'(act[l]); db_{l-1} = colsum(dz[l])
             memset(&g, 0, sizeof(g));
+            int ldb_pl[2] = {0, 0};
             for (int z = 0; z < 2; ++z) {
                 Net &n = p->net[z];
                 g.A[z] = n.dz[l + 1]; g.lda[z] = n.dims[l + 1];
@@ -131,8 +136,11 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
                 g.aux[z] = n.act[l]; g.ldaux[z] = n.dims[l];
                 g.colsum[z] = p->dev.grads + n.b_off[l - 1];
                 g.M[z] = M; g.N[z] = n.dims[l]; g.K[z] = n.dims[l + 1];
+                g.Bpl[z] = p->dev.wtpl + n.pl_off[l];            // W^T [k'][n]: reduction-contiguous rows of length dims[l+1]
+                ldb_pl[z] = n.dims[l + 1];
             }
-            ppok_gemm_dx(&g, 2, p->stream);
+            g.pl_stride = p->dev.pl_stride;
+            ppok_gemm_dx(&g, 2, ldb_pl, p->stream);
         }
     }
     if (p->overlap) {                                // join: the optimiser step (main stream) needs every dW
@@ -195,6 +203,20 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         }
     }
     d.num_params = off;
+    {   // bf16 plane layout: one segment per weight matrix, 16-byte aligned
+        int64_t po = 0;
+        d.nseg = 0;
+        for (int z = 0; z < 2; ++z)
+            for (int l = 0; l < p->net[z].nl; ++l) {
+                Net &n = p->net[z];
+                n.pl_off[l] = po;
+                d.seg_off[d.nseg] = n.w_off[l]; d.seg_pl[d.nseg] = po;
+                d.seg_rows[d.nseg] = n.dims[l + 1]; d.seg_cols[d.nseg] = n.dims[l];
+                ++d.nseg;
+                po += ((int64_t)n.dims[l + 1] * n.dims[l] + 7) / 8 * 8;
+            }
+        d.pl_stride = po;
+    }
     d.off_bias_actor_head = (int)p->net[0].b_off[p->net[0].nl - 1];
     d.off_bias_critic_head = (int)p->net[1].b_off[p->net[1].nl - 1];
     d.N = N; d.T = T; d.A = A; d.O = O; d.OC = OC; d.mb_rows = R;
@@ -206,6 +228,10 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     d.entropy_coef = cfg->entropy_coef; d.desired_kl = cfg->desired_kl; d.max_grad_norm = cfg->max_grad_norm;
 
     PA(d.params, off + 2); PA(d.grads, off + 2); PA(d.adam_m, off + 2); PA(d.adam_v, off + 2);
+    {
+        const int64_t pls = d.pl_stride;            // PA memsets through d.*: keep the stride across the allocation macros
+        PA(d.wpl, (size_t)3 * pls + 8); PA(d.wtpl, (size_t)3 * pls + 8);
+    }
     const size_t TN = (size_t)T * N;
     PA(d.st_obs, TN * O);
     if (cfg->num_critic_obs > 0) PA(d.st_critic_obs, TN * OC); else d.st_critic_obs = d.st_obs;
@@ -311,7 +337,8 @@ int lg_ppo_begin_update(lg_ppo *p) {
     (void)hipMemsetAsync(p->dev.stats + 5, 0, sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.loss_acc, 0, 4 * sizeof(float), p->stream);
     p->grads_dirty = 1;                      // first backward of this update clears the gradient buffer
-    return 0;
+    ppok_sync_planes(&p->dev, p->stream);    // weight planes follow whatever the fp32 parameters hold now
+    return launch_ok();
 }
 
 int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
@@ -327,7 +354,7 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     // fused head (forward + loss + backward of the two thin head layers) when both nets end in the same
     // supported width; otherwise head GEMMs + k_loss
     const bool fuse = nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32);   // at 128 the head GEMMs + k_loss measured faster (0.755 vs 0.773 ms)
-    forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0);
+    forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],
                         nc.w_off[nl - 1], nc.b_off[nl - 1], na.b_off[nl - 2], nc.b_off[nl - 2], p->stream);

@@ -10,7 +10,12 @@ struct GemmArgs {                  // up to 2 problems per launch (actor, critic
     float *C[2], *colsum[2];
     int M[2], N[2], K[2], lda[2], ldb[2], ldc[2], ldaux[2];
     int elu;
+    // B operand pre-split into three bf16 planes [n][k] (reduction contiguous), plane p at Bpl + p * pl_stride
+    const uint16_t *Bpl[2];
+    int64_t pl_stride;
 };
+
+#define LG_PPO_MAX_SEG (2 * LG_PPO_MAX_LAYERS)
 
 struct PpoDev {                    // passed by value to kernels
     int N, T, A, O, OC, mb_rows, world, env_offset;
@@ -30,4 +35,11 @@ struct PpoDev {                    // passed by value to kernels
     float *adv_partial;
     float *mb_obs, *mb_critic_obs, *mb_actions, *mb_mu, *mb_scalars;   // minibatch gathers; scalars = [v_old, ret, adv, logp_old]
     float *cur_reward_sum, *cur_episode_len, *ep_stats;                // per-env running sums; [sum_rew, sum_len, count] of finished episodes
+    // split-bf16 images of the weight matrices, maintained by the optimiser step: wpl = W [n][k], wtpl = W^T [k][n];
+    // three planes (h, m, l) pl_stride elements apart; segment s = one weight matrix (rows x cols at flat offset seg_off)
+    uint16_t *wpl, *wtpl;
+    int64_t pl_stride;
+    int nseg;
+    int64_t seg_off[LG_PPO_MAX_SEG], seg_pl[LG_PPO_MAX_SEG];
+    int seg_rows[LG_PPO_MAX_SEG], seg_cols[LG_PPO_MAX_SEG];
 };

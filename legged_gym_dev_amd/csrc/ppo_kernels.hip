@@ -245,36 +245,75 @@ __device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, 
     }
 }
 
-template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false>
+// B operand already split (weight planes kept by the optimiser step): the tile is three [ROWS][32] bf16 images,
+// staged as plain 16-byte copies -- no conversion work in the loop.  Chunk c of a tile: plane c / (ROWS*4),
+// row (c / 4) % ROWS, 16-byte quarter c % 4 of the row's 64 bytes.
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_load_pl(const uint16_t *__restrict__ src, int64_t pl_stride, int ld, int row0, int red0, int nrows,
+                                              int nred, uint4 (&regs)[ROWS * 12 / NT], unsigned &mask) {
+    constexpr int NV = ROWS * 12 / NT;
+    mask = 0u;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = threadIdx.x + v * NT;
+        const int pl = c / (ROWS * 4), r = (c >> 2) % ROWS, q = c & 3;
+        const int grow = row0 + r, gk = red0 + 8 * q;
+        const int rc_ = min(grow, nrows - 1), kc_ = min(gk, nred - 8);      // nred % 8 == 0 (checked by the launcher)
+        regs[v] = *reinterpret_cast<const uint4 *>(src + pl * pl_stride + (size_t)rc_ * ld + kc_);
+        mask |= (grow < nrows && gk < nred) ? (1u << v) : 0u;
+    }
+}
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_store_pl(unsigned char *__restrict__ lds, const uint4 (&regs)[ROWS * 12 / NT], unsigned mask) {
+    constexpr int NV = ROWS * 12 / NT;
+    constexpr int PL = x6_plane_bytes<ROWS>();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = threadIdx.x + v * NT;
+        const int pl = c / (ROWS * 4), r = (c >> 2) % ROWS, q = c & 3;
+        const bool in = (mask >> v) & 1u;
+        const uint4 x = in ? regs[v] : make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(lds + pl * PL + x6_prow<ROWS>(r) * X6_ROWB + 16 * q) = x;
+    }
+}
+
+template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false, bool B_PL = false>
 __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
                                                  int M, int N, int k_begin, int k_end, unsigned char *__restrict__ lds, int wm, int wn, int li,
-                                                 int lk, f32x16 (&acc)[TM][TN]) {
+                                                 int lk, f32x16 (&acc)[TM][TN], const uint16_t *__restrict__ Bpl = nullptr,
+                                                 int64_t pl_stride = 0) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
     constexpr int APL = x6_plane_bytes<BM>(), BPL = x6_plane_bytes<BN>();
     constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;
     // two register sets: the global loads of k-tile t+2 are issued before the MFMAs of tile t, and tile
     // t+1 (already landed) is split and stored after them -- one full iteration to cover the L2/HBM latency
+    constexpr int NVP = B_PL ? BN * 12 / NT : 1;
     float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
+    uint4 pb0[NVP], pb1[NVP];
     unsigned ma0, mb0, ma1 = 0, mb1 = 0;
     unsigned char *lds_b = lds + 3 * APL;
     stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin, M, k_end, ra0, ma0);
-    stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
+    if constexpr (B_PL) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, pb0, mb0);
+    else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
     if (k_begin + BK < k_end) {
         stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin + BK, M, k_end, ra1, ma1);
-        stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
+        if constexpr (B_PL) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin + BK, N, k_end, pb1, mb1);
+        else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
     }
     stage_store_x6<A_RC, BM, NT, FULL>(lds, ra0, ma0);
-    stage_store_x6<B_RC, BN, NT, FULL>(lds_b, rb0, mb0);
+    if constexpr (B_PL) stage_store_pl<BN, NT>(lds_b, pb0, mb0);
+    else stage_store_x6<B_RC, BN, NT, FULL>(lds_b, rb0, mb0);
     __syncthreads();
     // fragment of tile a, plane p, k-step s: base + a*8*X6_ROWB (32 logical rows = 8 physical) + p*PL + s*32
     const unsigned char *fa = lds + x6_prow<BM>(wm + li) * X6_ROWB + 16 * lk;
     const unsigned char *fb = lds_b + x6_prow<BN>(wn + li) * X6_ROWB + 16 * lk;
 
-    auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA], float4 (&yb)[NVB],
-                    unsigned &yma, unsigned &ymb) {
+    auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], uint4 (&xp)[NVP], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA],
+                    float4 (&yb)[NVB], uint4 (&yp)[NVP], unsigned &yma, unsigned &ymb) {
         if (k0 + 2 * BK < k_end) {
             stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k0 + 2 * BK, M, k_end, ya, yma);
-            stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
+            if constexpr (B_PL) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k0 + 2 * BK, N, k_end, yp, ymb);
+            else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
         }
         bf16x8 av[2][TM][3], bv[2][TN][3];
 #pragma unroll
@@ -317,18 +356,20 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
         __syncthreads();                         // every wave is done reading before the tile is refilled
         if (k0 + BK < k_end) {
             stage_store_x6<A_RC, BM, NT, FULL>(lds, xa, xma);
-            stage_store_x6<B_RC, BN, NT, FULL>(lds_b, xb, xmb);
+            if constexpr (B_PL) stage_store_pl<BN, NT>(lds_b, xp, xmb);
+            else stage_store_x6<B_RC, BN, NT, FULL>(lds_b, xb, xmb);
         }
         __syncthreads();
     };
     for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
-        body(k0, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
-        if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
+        body(k0, ra1, rb1, pb1, ma1, mb1, ra0, rb0, pb0, ma0, mb0);
+        if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, pb0, ma0, mb0, ra1, rb1, pb1, ma1, mb1);
     }
 }
 
-template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2>
+template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, bool B_PL = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) : 1) k_gemm(GemmArgs g) {
+    static_assert(!B_PL || (X6 && B_RC), "weight planes feed the split-bf16 mainloop as a reduction-contiguous operand");
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;       // WGM x WGN waves, each TM x TN tiles of 32x32
     static_assert(X6 || (WGM == 2 && WGN == 2), "the fp32-input mainloop is written for 2x2 waves");
     const int z = blockIdx.z;
@@ -372,6 +413,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
     if (X6) {
         // whole tile in range in all three dimensions (workgroup-uniform): staging without clamps and masks
         const bool full = a_vec && b_vec && m0 + BM <= M && n0 + BN <= N && ((k_end - k_begin) % BK) == 0;
+        if (B_PL) {
+            if (full) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            else if (a_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, false, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false, false, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+        } else
         if (full) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
         else if (a_vec && b_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
         else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
@@ -464,6 +510,30 @@ static int g_gemm_x6 = 1;     // split-bf16 mainloop (fp32 accuracy on the bf16 
 static int g_gemm_w8 = 1;     // 128x128 tile on 8 waves (2x4, each 64x32) instead of 4 waves (2x2, each 64x64)
 extern "C" void ppok_debug_set_x6(int v) { g_gemm_x6 = v & 1; g_gemm_w8 = (v >> 1) & 1; }
 
+static int g_gemm_planes = 1;  // forward / input-gradient GEMMs take the weight operand from the optimiser's bf16 planes
+extern "C" void ppok_debug_set_planes(int v) { g_gemm_planes = v; }
+
+// forward (EPI 0) and input gradient (EPI 1) with B = pre-split weight planes, reduction-contiguous
+template <int EPI>
+static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
+    int maxM = 0, maxN = 0;
+    for (int z = 0; z < nz; ++z) { maxM = g.M[z] > maxM ? g.M[z] : maxM; maxN = g.N[z] > maxN ? g.N[z] : maxN; }
+    const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
+    if (big_tiles >= 192 && maxN > 64 && maxM > 64) {
+        dim3 grid((unsigned)big_tiles, 1, nz);
+        hipLaunchKernelGGL((k_gemm<true, true, EPI, 2, 1, false, true, 2, 4, true>), grid, dim3(512), 0, s, g);
+    } else {
+        dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), 1, nz);
+        hipLaunchKernelGGL((k_gemm<true, true, EPI, 1, 1, false, true, 2, 2, true>), grid, dim3(256), 0, s, g);
+    }
+}
+static bool planes_ok(const GemmArgs &g, int nz) {
+    if (!g_gemm_planes || !g_gemm_x6) return false;
+    for (int z = 0; z < nz; ++z)
+        if (!g.Bpl[z] || (g.ldb[z] & 7) || (g.K[z] & 7) || g.K[z] < 8 || ((uintptr_t)g.Bpl[z] & 15) || (g.pl_stride & 7)) return false;
+    return true;
+}
+
 template <bool A_RC, bool B_RC, int EPI>
 static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
     int maxM = 0, maxN = 0;
@@ -482,8 +552,18 @@ static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
         else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, true>), grid, dim3(256), 0, s, g);
     }
 }
-extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) { launch_gemm<true, true, 0>(*g, nz, 1, s); }
-extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s) { launch_gemm<true, false, 1>(*g, nz, 1, s); }
+// g->Bpl (optional): planes of W [n][k] for the forward; for the input gradient planes of W^T [k'][n] with ldb = n --
+// the caller passes both B (fp32 W, layout of the plain path) and Bpl; whichever path is eligible is taken
+extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) {
+    if (planes_ok(*g, nz)) launch_gemm_pl<0>(*g, nz, s);
+    else launch_gemm<true, true, 0>(*g, nz, 1, s);
+}
+extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, const int *ldb_planes, hipStream_t s) {
+    GemmArgs h = *g;
+    if (ldb_planes) { for (int z = 0; z < nz; ++z) h.ldb[z] = ldb_planes[z]; }
+    if (ldb_planes && planes_ok(h, nz)) launch_gemm_pl<1>(h, nz, s);
+    else launch_gemm<true, false, 1>(*g, nz, 1, s);
+}
 extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s) { launch_gemm<false, false, 2>(*g, nz, splits, s); }
 
 // ------------------------------------------------------------------------------------------------
@@ -966,6 +1046,27 @@ __global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par) {
     }
     if (threadIdx.x == 0) atomicAdd(&P.loss_acc[2 + par], red[0]);
 }
+// split-bf16 images of parameter k (if it belongs to a weight matrix): W plane at [n][c], W^T plane at [c][n]
+__device__ __forceinline__ void write_planes(const PpoDev &P, int64_t k, float x) {
+    for (int s = 0; s < P.nseg; ++s) {
+        const int64_t rel = k - P.seg_off[s];
+        if (rel >= 0 && rel < (int64_t)P.seg_rows[s] * P.seg_cols[s]) {
+            const int n = (int)(rel / P.seg_cols[s]), c = (int)(rel % P.seg_cols[s]);
+            uint32_t h, m, l;
+            split2(x, 0.f, h, m, l);
+            const int64_t a = P.seg_pl[s] + rel, t = P.seg_pl[s] + (int64_t)c * P.seg_rows[s] + n;
+            P.wpl[a] = (uint16_t)h; P.wpl[P.pl_stride + a] = (uint16_t)m; P.wpl[2 * P.pl_stride + a] = (uint16_t)l;
+            P.wtpl[t] = (uint16_t)h; P.wtpl[P.pl_stride + t] = (uint16_t)m; P.wtpl[2 * P.pl_stride + t] = (uint16_t)l;
+            return;
+        }
+    }
+}
+// rebuild every plane from the fp32 parameters (begin of an update: parameters may have been written through
+// the zero-copy views -- checkpoint load, initial broadcast)
+__global__ void __launch_bounds__(256) k_sync_planes(PpoDev P) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)gridDim.x * blockDim.x)
+        write_planes(P, k, P.params[k]);
+}
 __global__ void __launch_bounds__(256) k_opt_adam(PpoDev P, int par) {
     const float total = sqrtf(P.loss_acc[2 + par]);
     const float coef = fminf(P.max_grad_norm / (total + 1e-6f), 1.0f);
@@ -978,8 +1079,10 @@ __global__ void __launch_bounds__(256) k_opt_adam(PpoDev P, int par) {
         const float v = 0.999f * P.adam_v[k] + 0.001f * g * g;
         P.adam_m[k] = m;
         P.adam_v[k] = v;
-        P.params[k] -= (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+        const float pn = P.params[k] - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+        P.params[k] = pn;
         P.grads[k] = 0.f;
+        write_planes(P, k, pn);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         P.grads[P.num_params] = 0.f; P.grads[P.num_params + 1] = 0.f;
@@ -1019,6 +1122,7 @@ int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, f
 void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s) {
     hipLaunchKernelGGL(k_loss, dim3((P->mb_rows + 255) / 256), dim3(256), 0, s, *P, mu, v, dmu, dval);
 }
+void ppok_sync_planes(const PpoDev *P, hipStream_t s) { hipLaunchKernelGGL(k_sync_planes, dim3(256), dim3(256), 0, s, *P); }
 void ppok_step(const PpoDev *P, int par, hipStream_t s) {
     hipLaunchKernelGGL(k_opt_prepare, dim3(128), dim3(256), 0, s, *P, par);
     hipLaunchKernelGGL(k_opt_adam, dim3(256), dim3(256), 0, s, *P, par);
