@@ -198,7 +198,7 @@ __device__ __forceinline__ void stage_store_x6(unsigned char *__restrict__ lds, 
     constexpr int NV = ROWS * BK / 4 / NT;
     constexpr int PL = x6_plane_bytes<ROWS>();
     const int tid = threadIdx.x;
-    if (RC) {
+    if constexpr (RC) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int idx = tid + v * NT;
@@ -514,14 +514,26 @@ static int g_gemm_planes = 1;  // forward / input-gradient GEMMs take the weight
 extern "C" void ppok_debug_set_planes(int v) { g_gemm_planes = v; }
 
 // forward (EPI 0) and input gradient (EPI 1) with B = pre-split weight planes, reduction-contiguous
+static int g_gemm_t96 = 1;     // allow the 96x128 tile when it fills the chip's 512 workgroup slots in fewer, or fuller, rounds
+extern "C" void ppok_debug_set_t96(int v) { g_gemm_t96 = v; }
+
 template <int EPI>
 static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
     int maxM = 0, maxN = 0;
     for (int z = 0; z < nz; ++z) { maxM = g.M[z] > maxM ? g.M[z] : maxM; maxN = g.N[z] > maxN ? g.N[z] : maxN; }
     const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
     if (big_tiles >= 192 && maxN > 64 && maxM > 64) {
-        dim3 grid((unsigned)big_tiles, 1, nz);
-        hipLaunchKernelGGL((k_gemm<true, true, EPI, 2, 1, false, true, 2, 4, true>), grid, dim3(512), 0, s, g);
+        // 256 CUs x 2 resident workgroups: time ~ rounds x tile area.  24576 rows in 128-row tiles give 768 or 384
+        // workgroups for the 256- and 128-wide layers (1.5 and 0.75 rounds); 96-row tiles give 1024 and 512.
+        const long t96 = (long)((maxM + 95) / 96) * ((maxN + 127) / 128);
+        const double c128 = (double)((big_tiles * nz + 511) / 512), c96 = 0.75 * (double)((t96 * nz + 511) / 512);
+        if (g_gemm_t96 && c96 < c128) {
+            dim3 grid((unsigned)t96, 1, nz);
+            hipLaunchKernelGGL((k_gemm<true, true, EPI, 3, 1, false, true, 1, 4, true>), grid, dim3(256), 0, s, g);
+        } else {
+            dim3 grid((unsigned)big_tiles, 1, nz);
+            hipLaunchKernelGGL((k_gemm<true, true, EPI, 2, 1, false, true, 2, 4, true>), grid, dim3(512), 0, s, g);
+        }
     } else {
         dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), 1, nz);
         hipLaunchKernelGGL((k_gemm<true, true, EPI, 1, 1, false, true, 2, 2, true>), grid, dim3(256), 0, s, g);

@@ -24,7 +24,7 @@ print("ms per minibatch fwd+bwd:", e0.elapsed_time(e1) / reps)
 if len(sys.argv) > 3:
     import ctypes
     for v in (0, 1, 0, 1):
-        ppo.lib.ppok_debug_set_planes(ctypes.c_int(v))
+        ppo.lib.ppok_debug_set_t96(ctypes.c_int(v))
         ppo._call("minibatch_backward", 0, 0)
         torch.cuda.synchronize()
         e0.record()
@@ -32,4 +32,4 @@ if len(sys.argv) > 3:
             ppo._call("minibatch_backward", 0, k % 4)
         e1.record()
         torch.cuda.synchronize()
-        print("weight planes", v, "ms:", e0.elapsed_time(e1) / reps)
+        print("96-row tiles", v, "ms:", e0.elapsed_time(e1) / reps)
