@@ -172,7 +172,7 @@ int lg_reset_all(lg_ctx *ctx);                                 /* reset_idx(aran
 typedef struct lg_ppo_cfg {
     int32_t num_envs, num_obs, num_critic_obs, num_actions;
     int32_t num_hidden, actor_hidden[LG_MAX_HIDDEN], critic_hidden[LG_MAX_HIDDEN];
-    int32_t activation /*0 elu (others rejected)*/, num_steps, num_epochs, num_mini_batches;
+    int32_t activation /*0 elu, 1 selu, 2 relu, 3 lrelu, 4 tanh, 5 sigmoid (rsl_rl get_activation; crelu rejected)*/, num_steps, num_epochs, num_mini_batches;
     int32_t adaptive_schedule, use_clipped_value_loss, world_size, _pad;
     uint64_t seed;
     float init_noise_std, value_loss_coef, clip_param, entropy_coef, learning_rate;

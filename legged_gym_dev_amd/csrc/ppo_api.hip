@@ -42,6 +42,7 @@ struct lg_ppo {
     hipStream_t side;                        // weight-gradient GEMMs run here, overlapping the input-gradient chain
     hipEvent_t ev_dz, ev_side;
     int overlap;
+    int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;                         // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
     int step, inject;
     int64_t act_count, update_count;
@@ -88,7 +89,7 @@ static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int ma
             g.M[k] = M; g.N[k] = n.dims[l + 1]; g.K[k] = n.dims[l];
             g.lda[k] = n.dims[l]; g.ldb[k] = n.dims[l]; g.ldc[k] = n.dims[l + 1];
         }
-        g.elu = l < nl - 1;
+        g.elu = l < nl - 1 ? p->act_code : 0;
         g.pl_stride = p->dev.pl_stride;
         ppok_gemm_fwd(&g, nz, p->stream);
     }
@@ -125,7 +126,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         } else {
             ppok_gemm_dw(&g, 2, splits, p->stream);
         }
-        if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * ELU'(act[l]); db_{l-1} = colsum(dz[l])
+        if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * act'(act[l]); db_{l-1} = colsum(dz[l])
             memset(&g, 0, sizeof(g));
             int ldb_pl[2] = {0, 0};
             for (int z = 0; z < 2; ++z) {
@@ -140,6 +141,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
                 ldb_pl[z] = n.dims[l + 1];
             }
             g.pl_stride = p->dev.pl_stride;
+            g.elu = p->act_code;                         // derivative of the hidden activation, through its output act[l]
             ppok_gemm_dx(&g, 2, ldb_pl, p->stream);
         }
     }
@@ -165,7 +167,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     if (!cfg || !out) { lg_set_error("null argument"); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { lg_set_error("no HIP device: no CPU fallback"); return -2; }
-    if (cfg->activation != 0) { lg_set_error("only activation='elu' is implemented"); return -3; }
+    if (cfg->activation < 0 || cfg->activation > 5) { lg_set_error("activation must be one of elu, selu, relu, lrelu, tanh, sigmoid (crelu changes the layer widths and is not implemented)"); return -3; }
     if (cfg->num_hidden < 1 || cfg->num_hidden > LG_MAX_HIDDEN || cfg->num_actions > LG_PPO_MAX_A) {
         lg_set_error("unsupported network size"); return -4;
     }
@@ -175,6 +177,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     lg_ppo *p = new lg_ppo();
     p->cfg = *cfg;
     p->stream = nullptr;
+    p->act_code = cfg->activation + 1;
     p->overlap = 1;
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
@@ -353,7 +356,7 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     const int nl = na.nl, H3 = na.dims[nl - 1];
     // fused head (forward + loss + backward of the two thin head layers) when both nets end in the same
     // supported width; otherwise head GEMMs + k_loss
-    const bool fuse = nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32);   // at 128 the head GEMMs + k_loss measured faster (0.755 vs 0.773 ms)
+    const bool fuse = p->act_code == 1 && nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32);   // at 128 the head GEMMs + k_loss measured faster (0.755 vs 0.773 ms)
     forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],

@@ -8,6 +8,34 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Hidden-layer activations of rsl_rl's get_activation (ActorCritic cfg `activation`, legged_robot_config.py:244):
+// code 0 none, 1 elu, 2 selu, 3 relu, 4 lrelu (slope 0.01), 5 tanh, 6 sigmoid.  act_bwd is the derivative expressed
+// through the activation's OUTPUT a (the only thing the forward pass keeps).
+#define SELU_L 1.0507009873554804934193349852946f
+#define SELU_LA (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f)
+__device__ __forceinline__ float act_fwd(int code, float v) {
+    switch (code) {
+    case 1: return v > 0.f ? v : __expf(v) - 1.0f;
+    case 2: return v > 0.f ? SELU_L * v : SELU_LA * (__expf(v) - 1.0f);
+    case 3: return fmaxf(v, 0.f);
+    case 4: return v > 0.f ? v : 0.01f * v;
+    case 5: return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * v)) - 1.0f;
+    case 6: return __frcp_rn(1.0f + __expf(-v));
+    default: return v;
+    }
+}
+__device__ __forceinline__ float act_bwd(int code, float a) {
+    switch (code) {
+    case 1: return a > 0.f ? 1.0f : a + 1.0f;
+    case 2: return a > 0.f ? SELU_L : a + SELU_LA;
+    case 3: return a > 0.f ? 1.0f : 0.f;
+    case 4: return a > 0.f ? 1.0f : 0.01f;
+    case 5: return 1.0f - a * a;
+    case 6: return a * (1.0f - a);
+    default: return 1.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = opA(A) . opB(B), K = reduction length.  A_RC: A stored [m][k] (reduction contiguous),
 // else [k][m].  B_RC: B stored [n][k], else [k][n].  4 waves as 2x2, each TM x TN tiles of 32x32
@@ -16,8 +44,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // LDS tiles keep the global layout (so the global->LDS copy is a straight 16-byte move) with a
 // one-float row pad; fragments are ds_read_b32 with lanes on consecutive rows/columns, which is
 // bank-conflict free in both layouts and far below the LDS rate at 64 cycles per fp32 MFMA.
-// EPI 0: C = (acc + bias[n]) then ELU if elu      (forward, nn.Linear + ELU)
-// EPI 1: C = acc * ELU'(aux[m][n]); colsum[n] += sum_m C   (input gradient + bias gradient below)
+// EPI 0: C = act(acc + bias[n]), act = g.elu code (forward, nn.Linear + activation; 0 on the head layer)
+// EPI 1: C = acc * act'(aux[m][n]); colsum[n] += sum_m C   (input gradient + bias gradient below)
 // EPI 2: C += acc via float atomics, reduction split over blockIdx.y   (weight gradient)
 #define BK 32
 
@@ -429,7 +457,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
     // ---- epilogue.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float *__restrict__ C = g.C[z];
     const bool interior = (m0 + BM <= M) && (n0 + BN <= N);     // workgroup-uniform
-    const int elu = g.elu;
+    const int elu = g.elu;                                      // activation code (workgroup-uniform)
     if (interior) {
         // unguarded path: loads of the epilogue operand are issued as one batch (no per-element branch,
         // which would serialise them behind s_waitcnt vmcnt(0)), then compute + store
@@ -453,10 +481,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
                     float v = acc[a][b][r];
                     if (EPI == 0) {
                         v += bias;
-                        if (elu) v = v > 0.f ? v : __expf(v) - 1.0f;
+                        v = act_fwd(elu, v);
                         *cp = v;
                     } else if (EPI == 1) {
-                        v *= aux[r] > 0.f ? 1.0f : aux[r] + 1.0f;
+                        v *= act_bwd(elu, aux[r]);
                         *cp = v;
                         csum += v;
                     } else {
@@ -485,11 +513,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
                     float v = acc[a][b][r];
                     if (EPI == 0) {
                         v += bias;
-                        if (elu) v = v > 0.f ? v : __expf(v) - 1.0f;
+                        v = act_fwd(elu, v);
                         C[(size_t)m * ldc + n] = v;
                     } else if (EPI == 1) {
                         const float act = g.aux[z][(size_t)m * g.ldaux[z] + n];
-                        v *= act > 0.f ? 1.0f : act + 1.0f;
+                        v *= act_bwd(elu, act);
                         C[(size_t)m * ldc + n] = v;
                         csum += v;
                     } else {
@@ -1148,6 +1176,6 @@ extern "C" void ppok_debug_gemm(const float *A, const float *B, float *C, int M,
     memset(&g, 0, sizeof(g));
     g.A[0] = A; g.B[0] = B; g.C[0] = C; g.M[0] = M; g.N[0] = N; g.K[0] = K; g.ldc[0] = N;
     if (mode == 0) { g.lda[0] = K; g.ldb[0] = K; launch_gemm<true, true, 0>(g, 1, 1, (hipStream_t)stream); }
-    else if (mode == 1) { g.lda[0] = K; g.ldb[0] = N; g.aux[0] = C; g.ldaux[0] = N; launch_gemm<true, false, 1>(g, 1, 1, (hipStream_t)stream); }
+    else if (mode == 1) { g.lda[0] = K; g.ldb[0] = N; g.aux[0] = C; g.ldaux[0] = N; g.elu = 1; launch_gemm<true, false, 1>(g, 1, 1, (hipStream_t)stream); }
     else { g.lda[0] = M; g.ldb[0] = N; launch_gemm<false, false, 2>(g, 1, splits, (hipStream_t)stream); }
 }

@@ -80,10 +80,11 @@ def build_mlp(state_dict, prefix="actor", activation="elu"):
     return torch.nn.Sequential(layers)
 
 
-def export_policy_as_jit(actor_critic, path, activation="elu"):
+def export_policy_as_jit(actor_critic, path, activation=None):
     """helpers.py:274-285: ``<path>/policy_1.pt`` = torch.jit.script(actor MLP on CPU)."""
     os.makedirs(path, exist_ok=True)
     sd = actor_critic.state_dict()
+    activation = activation or getattr(actor_critic, "activation", "elu")
     model = copy.deepcopy(build_mlp(sd, "actor", activation)).to("cpu")
     scripted = torch.jit.script(model)
     out = os.path.join(path, "policy_1.pt")

@@ -18,6 +18,9 @@ def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_ACTIVATIONS = {"elu": 0, "selu": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}
+
+
 class HipPPO:
     def __init__(self, num_envs, num_obs, num_critic_obs, num_actions, policy_cfg, alg_cfg, num_steps,
                  device="cuda:0", seed=1, world_size=1, rank=0):
@@ -29,8 +32,10 @@ class HipPPO:
         ah, ch = list(policy_cfg["actor_hidden_dims"]), list(policy_cfg["critic_hidden_dims"])
         if len(ah) != len(ch) or len(ah) > capi.MAX_HIDDEN:
             raise ValueError("actor/critic need the same number (<=4) of hidden layers")
-        if policy_cfg.get("activation", "elu") != "elu":
-            raise NotImplementedError("only activation='elu' has HIP kernels")
+        self.activation = policy_cfg.get("activation", "elu")
+        if self.activation not in _ACTIVATIONS:
+            raise NotImplementedError(f"activation {self.activation!r}: HIP epilogues exist for {sorted(_ACTIVATIONS)} "
+                                      "(crelu doubles the layer widths and is not implemented)")
         c = capi.lg_ppo_cfg()
         c.num_envs, c.num_obs, c.num_actions = num_envs, num_obs, num_actions
         self.privileged = num_critic_obs is not None and num_critic_obs != num_obs
@@ -38,7 +43,7 @@ class HipPPO:
         c.num_hidden = len(ah)
         for i, (a, b) in enumerate(zip(ah, ch)):
             c.actor_hidden[i], c.critic_hidden[i] = a, b
-        c.activation = 0
+        c.activation = _ACTIVATIONS[self.activation]
         c.num_steps = num_steps
         c.num_epochs, c.num_mini_batches = alg_cfg["num_learning_epochs"], alg_cfg["num_mini_batches"]
         c.adaptive_schedule = int(alg_cfg.get("schedule", "adaptive") == "adaptive" and alg_cfg.get("desired_kl") is not None)

@@ -31,6 +31,7 @@ class ActorCriticFacade:
     def __init__(self, ppo):
         self._ppo = ppo
         self.actor = _ActorFacade(ppo)
+        self.activation = ppo.activation
 
     @property
     def std(self):

@@ -17,12 +17,13 @@ class ActorCritic(nn.Module):
     def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256),
                  critic_hidden_dims=(256, 256, 256), activation="elu", init_noise_std=1.0):
         super().__init__()
-        assert activation == "elu"
+        act = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
+               "sigmoid": nn.Sigmoid}[activation]                # rsl_rl get_activation (crelu not covered)
 
         def mlp(i, hidden, o):
             layers, d = [], i
             for h in hidden:
-                layers += [nn.Linear(d, h), nn.ELU()]
+                layers += [nn.Linear(d, h), act()]
                 d = h
             layers.append(nn.Linear(d, o))
             return nn.Sequential(*layers)

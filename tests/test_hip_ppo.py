@@ -19,7 +19,7 @@ def _make(N, O, A, T, policy=POLICY, alg=ALG, seed=3):
     from oracle import ppo_torch
     torch.manual_seed(seed)
     hip = HipPPO(N, O, None, A, policy, alg, T, device="cuda:0", seed=seed)
-    ac = ppo_torch.ActorCritic(O, O, A, policy["actor_hidden_dims"], policy["critic_hidden_dims"], "elu",
+    ac = ppo_torch.ActorCritic(O, O, A, policy["actor_hidden_dims"], policy["critic_hidden_dims"], policy.get("activation", "elu"),
                                policy["init_noise_std"]).cuda()
     sd = {k: v.clone() for k, v in hip.state_dict().items()}
     ac.load_state_dict(sd)
@@ -214,3 +214,41 @@ def test_split_bf16_gemm_is_fp32_accurate(mode, M, N, K):
         lib.ppok_debug_set_x6(ctypes.c_int(3))
     bound = 2.0 * err[0] + 2.0 ** -22 * float(ref.abs().max())
     assert err[1] <= bound and err[3] <= bound, err
+
+
+@pytest.mark.parametrize("activation", ["selu", "relu", "lrelu", "tanh", "sigmoid"])
+def test_other_activations_forward_and_gradients(activation):
+    """ActorCritic `activation` values other than elu (legged_robot_config.py:244; crelu excluded): inference
+    means and one minibatch's gradients (GEMM epilogues act / act' computed from the stored outputs) against
+    autograd on the torch restatement.  Tolerances as for elu: 2e-4 on means, 2e-3 relative / 2e-4 of the
+    gradient scale absolute on gradients."""
+    N, O, A, T = 256, 48, 12, 8
+    policy = dict(POLICY, actor_hidden_dims=[96, 64, 32], critic_hidden_dims=[96, 64, 32], activation=activation)
+    alg = dict(ALG, num_mini_batches=1)
+    hip, ac, pt = _make(N, O, A, T, policy, alg)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(11)
+        obs = torch.randn(N, O, device="cuda", generator=g)
+        np.testing.assert_allclose(hip.act_inference(obs).cpu().numpy(), ac.actor(obs).detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+        _fill_rollout(hip, ac, T, N, O, A, g)
+        hip.compute_returns(torch.randn(N, O, device="cuda", generator=g))
+        hip._call("begin_update")
+        torch.cuda.synchronize()
+        idx = hip.t["perm"].long()[: T * N]
+        hip._call("minibatch_backward", 0, 0)
+        algo = pt.PPO(ac, clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-3, max_grad_norm=1.0,
+                      use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01)
+        flat = lambda name: hip.t[name].reshape(T * N, *hip.t[name].shape[2:])
+        R = T * N
+        batch = (flat("obs")[idx], flat("obs")[idx], flat("actions")[idx], flat("values")[idx].unsqueeze(-1),
+                 flat("advantages")[idx].unsqueeze(-1), flat("returns")[idx].unsqueeze(-1),
+                 flat("log_prob")[idx].unsqueeze(-1), flat("mu")[idx], hip.t["sigma"].clone().expand(R, A))
+        ac.zero_grad()
+        loss, kl, vl, sl = algo.minibatch_loss(*(b.clone() for b in batch))
+        loss.backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in ac.parameters()])
+        got = hip.t["grads"][: hip.num_params]
+        torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max()))
+        assert float((got - ref).norm() / ref.norm()) < 3e-4
+    finally:
+        hip.close()
