@@ -89,7 +89,8 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
             int l = model->sph_link[k];
             if (l < 0) {
                 int b = h.n_base_spheres++;
-                if (b >= L) { g_err = "more base collision spheres than legs"; delete c; return -8; }
+                if (b >= L * LG_MAX_BASE_PER_LANE) { g_err = "too many collision spheres on the base"; delete c; return -8; }
+                if (b > 0 && model->sph_body[k] != h.base_body[0]) { g_err = "base collision spheres report to different bodies"; delete c; return -8; }
                 h.base_body[b] = model->sph_body[k];
                 memcpy(h.base_center[b], model->sph_center[k], 12);
                 h.base_radius[b] = model->sph_radius[k];
@@ -120,8 +121,13 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
                 memcpy(t + LG_LT_SLOTS + 4 * s, h.slot_center[s][l], 12);
                 t[LG_LT_SLOTS + 4 * s + 3] = h.slot_radius[s][l];
             }
-            memcpy(t + LG_LT_BASE, h.base_center[l], 12);
-            t[LG_LT_BASE + 3] = h.base_radius[l];
+            for (int u = 0; u < LG_MAX_BASE_PER_LANE; ++u) {
+                const int b = l + u * L;
+                if (b < h.n_base_spheres) {
+                    memcpy(t + LG_LT_BASE + 4 * u, h.base_center[b], 12);
+                    t[LG_LT_BASE + 4 * u + 3] = h.base_radius[b];
+                }
+            }
         }
     }
 

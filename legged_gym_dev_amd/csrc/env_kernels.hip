@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64, 1) k_physics(const DevParams *__restrict__
             const int dyn = m.body_dyn[b];
             if ((dyn < 0 ? 0 : dyn / J) == leg) { cf[3 * b] = 0.f; cf[3 * b + 1] = 0.f; cf[3 * b + 2] = 0.f; }
         }
-    __shared__ float s_ct[(LG_MAX_LEG_SLOTS + 1) * LG_CT_NF * 64];
+    __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
     __shared__ float s_lt[L * LG_LT_STRIDE];                // per-leg model constants: one coalesced copy per launch
     for (int t = threadIdx.x; t < L * LG_LT_STRIDE; t += 64) s_lt[t] = (&P->leg_tab[0][0])[t];
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     const int N = c.num_envs, B = c.num_bodies;
     const int env0 = blockIdx.x * EPW;
     const int nrow = min(ROWS, (N - env0) * A);              // live rows of this block
-    __shared__ float s_ct[(LG_MAX_LEG_SLOTS + 1) * LG_CT_NF * 64];
+    __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
     __shared__ float s_lt[L * LG_LT_STRIDE];
     __shared__ float s_w[LSTM ? LG_LSTM_NW : 1];

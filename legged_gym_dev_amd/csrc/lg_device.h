@@ -8,14 +8,16 @@
 #define LG_WAVE 64
 #define LG_TILE_THREADS 256
 #define LG_MAX_LEG_SLOTS 6
+#define LG_MAX_BASE_PER_LANE 2      // base collision spheres are dealt to the lanes of an env: sphere b -> lane b % L, slot b / L
+#define LG_NUM_SLOTS (LG_MAX_LEG_SLOTS + LG_MAX_BASE_PER_LANE)
 // per-leg constant table: joint j at LG_LT_JOINT*j: R_pj 0..8, p_pj 9..11, axis 12..14, child-link inertia 15..23,
 // com 24..26, mass 27, joint damping 28, velocity limit 29; then sphere slot s: centre 3 + radius; then the
-// base sphere of this lane.  Stride odd in 4-byte words: the L legs of a wave sit in different LDS banks.
+// base spheres of this lane (radius 0 = none).  Stride odd in 4-byte words: the L legs of a wave sit in different LDS banks.
 #define LG_LT_JOINT 30
 #define LG_LT_MAXJ 6
 #define LG_LT_SLOTS (LG_LT_JOINT * LG_LT_MAXJ)
 #define LG_LT_BASE (LG_LT_SLOTS + 4 * LG_MAX_LEG_SLOTS)
-#define LG_LT_STRIDE (LG_LT_BASE + 4 + 1)
+#define LG_LT_STRIDE (LG_LT_BASE + 4 * LG_MAX_BASE_PER_LANE + 1)
 
 // Everything a kernel needs, resident in HBM and passed by pointer: uniform (scalar-unit) loads.
 struct DevParams {
@@ -36,9 +38,9 @@ struct DevParams {
     int slot_body[LG_MAX_SPHERES][4 + 4];    // [slot][leg] body row (legs <= 8)
     float slot_center[LG_MAX_SPHERES][8][3];
     float slot_radius[LG_MAX_SPHERES][8];
-    int base_body[8];
-    float base_center[8][3];
-    float base_radius[8];
+    int base_body[8 * LG_MAX_BASE_PER_LANE];
+    float base_center[8 * LG_MAX_BASE_PER_LANE][3];
+    float base_radius[8 * LG_MAX_BASE_PER_LANE];
     // every model constant one (env, leg) lane of the physics reads, flattened per leg (host-built once;
     // the kernel copies it into LDS with one coalesced pass): LG_LT_* offsets below
     float leg_tab[8][LG_LT_STRIDE];

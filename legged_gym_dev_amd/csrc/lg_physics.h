@@ -286,17 +286,18 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     unsigned long long link_pk = 0ull;
     for (int s = 0; s < nslots; ++s) link_pk |= (unsigned long long)(P->slot_link[s] & 15) << (4 * s);
     // (1) detection over every slot: geometry only
-    for (int s = 0; s <= nslots; ++s) {
-        const bool is_base = (s == nslots);
-        const int si = is_base ? LG_MAX_LEG_SLOTS : s;
-        const bool exists = is_base ? (leg < P->n_base_spheres) : true;
+    for (int s = 0; s < nslots + LG_MAX_BASE_PER_LANE; ++s) {
+        const bool is_base = s >= nslots;
+        const int ub = s - nslots;                              // which of this lane's base spheres
+        const int si = is_base ? LG_MAX_LEG_SLOTS + ub : s;
+        const bool exists = is_base ? (leg + ub * L < P->n_base_spheres) : true;
         V3 cbk = {0.f, 0.f, 0.f}, Pc = {0.f, 0.f, 0.f}, nb = {0.f, 0.f, 1.f};
         float rad = 0.f, vtarget = 0.f;
         bool active = false;
         if (exists) {
             if (is_base) {
-                cbk = ld3(lt + LG_LT_BASE);
-                rad = lt[LG_LT_BASE + 3];
+                cbk = ld3(lt + LG_LT_BASE + 4 * ub);
+                rad = lt[LG_LT_BASE + 4 * ub + 3];
             } else {
                 const int jl = P->slot_link[s];
                 M3 Rk;
@@ -329,7 +330,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
         const bool valid = rem != 0u;
         const int si = valid ? __ffs(rem) - 1 : 0;
-        const int jl = (si == LG_MAX_LEG_SLOTS) ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
+        const int jl = (si >= LG_MAX_LEG_SLOTS) ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
         const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
         V3 t1, t2;
         tangents(nb, t1, t2);
@@ -363,8 +364,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             CF(si, 11) = Wc[2][2] > 1e-9f ? __frcp_rn(Wc[2][2]) : 0.f;
         }
     }
-    const bool base_active = (amask >> LG_MAX_LEG_SLOTS) & 1u;
-    const int n_base_active = (int)leg_sum<L>(base_active ? 1.0f : 0.0f);
+    const int n_base_active = (int)leg_sum<L>((float)__popc(amask >> LG_MAX_LEG_SLOTS));
     const int n_leg_active = __popc(amask & ((1u << LG_MAX_LEG_SLOTS) - 1u));
     const float rl = __frcp_rn((float)max(n_leg_active, 1)), rb = __frcp_rn((float)max(n_base_active, 1));
 
@@ -377,7 +377,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
                 const bool active = rem != 0u;
                 const int si = active ? __ffs(rem) - 1 : 0;
-                const bool is_base = si == LG_MAX_LEG_SLOTS;
+                const bool is_base = si >= LG_MAX_LEG_SLOTS;
                 const int jl = is_base ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
                 Sv vl = velf0;
 #pragma unroll
@@ -430,8 +430,9 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     }
 
     // ---- contact forces out (world frame, N)
+    fbase = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int si = 0; si <= LG_MAX_LEG_SLOTS; ++si) {
+    for (int si = 0; si < LG_NUM_SLOTS; ++si) {
         V3 f = {0.f, 0.f, 0.f};
         if ((amask >> si) & 1u) {
             const V3 nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
@@ -439,7 +440,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             tangents(nb, t1, t2);
             f = inv_dt * mul(Rb, CF(si, 13) * nb + CF(si, 14) * t1 + CF(si, 15) * t2);
         }
-        if (si == LG_MAX_LEG_SLOTS) fbase = f; else fslot[si] = f;
+        if (si >= LG_MAX_LEG_SLOTS) fbase = fbase + f; else fslot[si] = f;
     }
 #undef CF
 #undef LK

@@ -1,4 +1,4 @@
-"""Task registrations of the hot-path scope (reference: legged_gym/envs/__init__.py:53-54,59)."""
+"""Task registrations (reference: legged_gym/envs/__init__.py:53-59): the hot-path tasks plus the A1 / ANYmal-B robots."""
 from legged_gym_dev_amd.utils.task_registry import task_registry
 from .base.legged_robot import LeggedRobot
 from .anymal_c.anymal import Anymal
@@ -6,7 +6,11 @@ from .anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, Anym
 from .anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
 from .cassie.cassie import Cassie
 from .cassie.cassie_config import CassieRoughCfg, CassieRoughCfgPPO
+from .a1.a1_config import A1RoughCfg, A1RoughCfgPPO
+from .anymal_b.anymal_b_config import AnymalBRoughCfg, AnymalBRoughCfgPPO
 
 task_registry.register("anymal_c_rough", Anymal, AnymalCRoughCfg(), AnymalCRoughCfgPPO())
 task_registry.register("anymal_c_flat", Anymal, AnymalCFlatCfg(), AnymalCFlatCfgPPO())
 task_registry.register("cassie", Cassie, CassieRoughCfg(), CassieRoughCfgPPO())
+task_registry.register("anymal_b", Anymal, AnymalBRoughCfg(), AnymalBRoughCfgPPO())
+task_registry.register("a1", LeggedRobot, A1RoughCfg(), A1RoughCfgPPO())

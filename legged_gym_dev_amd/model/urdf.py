@@ -211,6 +211,18 @@ def load_urdf(path: str, collapse_fixed_joints: bool = True,
                     spheres.append({"body": bi, "center": s["p"] + o * zaxis, "radius": s["radius"]})
             elif s["type"] == "box":
                 hx, hy, hz = 0.5 * s["size"]
+                h = np.array([hx, hy, hz])
+                order = np.argsort(h)
+                if h[order[2]] >= 2.5 * h[order[1]]:
+                    # a bar (A1 thigh / calf): spheres along its long axis, like a capsule of the bar's mean half-width
+                    rad = 0.5 * (h[order[0]] + h[order[1]])
+                    axis = np.zeros(3)
+                    axis[order[2]] = 1.0
+                    reach = h[order[2]] - rad
+                    offs = [-reach, reach] if 2 * reach < 0.3 else [-reach, 0.0, reach]
+                    for o in offs:
+                        spheres.append({"body": bi, "center": s["p"] + s["R"] @ (o * axis), "radius": float(rad)})
+                    continue
                 rad = 0.25 * min(hx, hy, hz) + 1e-3
                 for sx in (-1, 1):
                     for sy in (-1, 1):

@@ -270,7 +270,7 @@ def _load_reference_modules():
     lg.envs = envs
     for p in ("legged_gym.envs.base", "legged_gym.utils", "legged_gym.envs.anymal_c",
               "legged_gym.envs.anymal_c.mixed_terrains", "legged_gym.envs.anymal_c.flat",
-              "legged_gym.envs.cassie"):
+              "legged_gym.envs.cassie", "legged_gym.envs.a1", "legged_gym.envs.anymal_b"):
         pkg(p)
 
     def load(fullname, rel):
@@ -296,7 +296,10 @@ def _load_reference_modules():
     any_ = load("legged_gym.envs.anymal_c.anymal", "legged_gym/envs/anymal_c/anymal.py")
     cas = load("legged_gym.envs.cassie.cassie", "legged_gym/envs/cassie/cassie.py")
     cascfg = load("legged_gym.envs.cassie.cassie_config", "legged_gym/envs/cassie/cassie_config.py")
-    return {"LeggedRobot": lr.LeggedRobot, "Anymal": any_.Anymal, "Cassie": cas.Cassie,
+    a1cfg = load("legged_gym.envs.a1.a1_config", "legged_gym/envs/a1/a1_config.py")
+    abcfg = load("legged_gym.envs.anymal_b.anymal_b_config", "legged_gym/envs/anymal_b/anymal_b_config.py")
+    return {"A1RoughCfg": a1cfg.A1RoughCfg, "AnymalBRoughCfg": abcfg.AnymalBRoughCfg,
+            "LeggedRobot": lr.LeggedRobot, "Anymal": any_.Anymal, "Cassie": cas.Cassie,
             "AnymalCRoughCfg": rough.AnymalCRoughCfg, "AnymalCFlatCfg": flat.AnymalCFlatCfg,
             "CassieRoughCfg": cascfg.CassieRoughCfg, "Terrain": terr.Terrain,
             "LeggedRobotCfg": cfgm.LeggedRobotCfg,
@@ -722,6 +725,17 @@ def main():
         cfg.control.use_actuator_network = False
         cfg.control.control_type = ct
         make_case(ref, f"anymal_c_pd_{ct}", "anymal_c", cfg, ref["Anymal"], 2, seed, "default")
+
+    # the other registered quadrupeds: A1 = plain LeggedRobot with the PD law, ANYmal-B = Anymal class
+    cfg = ref["A1RoughCfg"]()
+    cfg.env.num_envs = 32
+    small_terrain(cfg)
+    make_case(ref, "a1", "a1", cfg, ref["LeggedRobot"], 4, 17, "limits")
+
+    cfg = ref["AnymalBRoughCfg"]()
+    cfg.env.num_envs = 32
+    small_terrain(cfg)
+    make_case(ref, "anymal_b", "anymal_b", cfg, ref["Anymal"], 3, 18, "default")
 
     lstm_fixture()
 

@@ -17,7 +17,7 @@ from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float  # noq
 from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FIXTURES = ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_allrewards", "anymal_c_pd_V", "anymal_c_pd_T"]
+FIXTURES = ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_allrewards", "anymal_c_pd_V", "anymal_c_pd_T", "a1", "anymal_b"]
 
 
 def load_fixture(name):
@@ -66,6 +66,16 @@ def make_cfg(name):
             setattr(cfg.rewards.scales, k, v)
         cfg.terrain.measure_heights = True
         cfg.env.num_observations = 235
+    elif name == "a1":
+        from legged_gym_dev_amd.envs.a1.a1_config import A1RoughCfg
+        cfg = A1RoughCfg()
+        cfg.env.num_envs = 32
+        _small_terrain(cfg)
+    elif name == "anymal_b":
+        from legged_gym_dev_amd.envs.anymal_b.anymal_b_config import AnymalBRoughCfg
+        cfg = AnymalBRoughCfg()
+        cfg.env.num_envs = 32
+        _small_terrain(cfg)
     elif name.startswith("anymal_c_pd_"):
         cfg = AnymalCFlatCfg()
         cfg.env.num_envs = 32

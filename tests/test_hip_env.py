@@ -62,7 +62,7 @@ def _seed_state(envs, rng, n, A, z0, origins=None, spread=0.02):
 
 
 @pytest.mark.parametrize("name,z0", [("anymal_c_flat", 0.50), ("anymal_c_rough", 0.55), ("cassie", 0.85),
-                                     ("anymal_c_allrewards", 0.30)])
+                                     ("anymal_c_allrewards", 0.30), ("a1", 0.28), ("anymal_b", 0.50)])
 def test_physics_substep_matches_oracle(name, z0, oracle_built):
     """One sim_dt of ABA + contact: HIP lane-parallel kernel vs the scalar oracle.
     Tolerance: 2e-4 abs/rel on state, 0.5 N + 2e-3 rel on contact forces (fp32, different
@@ -71,7 +71,7 @@ def test_physics_substep_matches_oracle(name, z0, oracle_built):
     try:
         rng = np.random.default_rng(3)
         n, A = 256, meta["num_dofs"]
-        origins = z["const_env_origins_init"][rng.integers(0, 64, n)] if meta["custom_origins"] else None
+        origins = z["const_env_origins_init"][rng.integers(0, len(z["const_env_origins_init"]), n)] if meta["custom_origins"] else None
         _seed_state([hip, ora], rng, n, A, z0, origins)
         tau = rng.uniform(-20, 20, (n, A)).astype(np.float32)
         n_contact = 0
@@ -94,7 +94,7 @@ def test_physics_substep_matches_oracle(name, z0, oracle_built):
         ora.close()
 
 
-@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie", "a1", "anymal_b"])
 def test_full_step_philox_matches_oracle(name, oracle_built):
     """lg_step with the built-in Philox streams (no injection) vs the oracle on the same seed:
     masks / counters bit-exact, fp32 state within tolerance per policy step."""
@@ -104,9 +104,9 @@ def test_full_step_philox_matches_oracle(name, oracle_built):
         n, A = 128, meta["num_dofs"]
         for e in (hip, ora):
             if meta["custom_origins"]:
-                e.set("env_origins", z["const_env_origins_init"][np.arange(n) % 64])
-                e.set("terrain_levels", z["const_terrain_levels_init"][np.arange(n) % 64])
-                e.set("terrain_types", z["const_terrain_types"][np.arange(n) % 64])
+                e.set("env_origins", z["const_env_origins_init"][np.arange(n) % len(z["const_env_origins_init"])])
+                e.set("terrain_levels", z["const_terrain_levels_init"][np.arange(n) % len(z["const_terrain_levels_init"])])
+                e.set("terrain_types", z["const_terrain_types"][np.arange(n) % len(z["const_terrain_types"])])
             e.set_step_counter(0)
             e.inject(0)
             e.call("reset_all")
@@ -177,7 +177,7 @@ def test_rollout_properties_at_baseline_size():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_pd_V", "anymal_c_rough", "cassie"])
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_pd_V", "anymal_c_rough", "cassie", "a1", "anymal_b"])
 def test_fused_control_loop_equals_launch_per_substep(name):
     """lg_step's single-launch control loop (k_substeps: clip + decimation x {torque law, physics} with the
     state resident on chip) against the operator-level sequence lg_set_actions / lg_compute_torques /
@@ -209,9 +209,9 @@ def test_fused_control_loop_equals_launch_per_substep(name):
         dec = int(cfg.control.decimation)
         if meta["custom_origins"]:
             for e in (a, b):
-                e.set("env_origins", z["const_env_origins_init"][np.arange(n) % 64])
-                e.set("terrain_levels", z["const_terrain_levels_init"][np.arange(n) % 64])
-                e.set("terrain_types", z["const_terrain_types"][np.arange(n) % 64])
+                e.set("env_origins", z["const_env_origins_init"][np.arange(n) % len(z["const_env_origins_init"])])
+                e.set("terrain_levels", z["const_terrain_levels_init"][np.arange(n) % len(z["const_terrain_levels_init"])])
+                e.set("terrain_types", z["const_terrain_types"][np.arange(n) % len(z["const_terrain_types"])])
                 e.call("reset_all")
         for t in range(6):
             act = (rng.uniform(-3, 3, (n, A)) * (200.0 if t == 5 else 1.0)).astype(np.float32)   # the last step exercises the action clip

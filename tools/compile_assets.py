@@ -29,6 +29,8 @@ from legged_gym_dev_amd.model import urdf  # noqa: E402
 ROBOTS = {
     "anymal_c": "resources/robots/anymal_c/urdf/anymal_c.urdf",
     "cassie": "resources/robots/cassie/urdf/cassie.urdf",
+    "a1": "resources/robots/a1/urdf/a1.urdf",
+    "anymal_b": "resources/robots/anymal_b/urdf/anymal_b.urdf",
 }
 LSTM_LAYOUT = [("in_scale", (2,)), ("out_scale", (1,)),
                ("weight_ih_l0", (32, 2)), ("weight_hh_l0", (32, 8)),
