@@ -1,6 +1,8 @@
 """End-to-end learning sanity on the GPU.
 
-    python tools/train_sanity.py ITERS [HIDDEN] [MODE]
+    python tools/train_sanity.py ITERS [HIDDEN] [MODE] [ROBOT]
+
+ROBOT "anymal_c" (default, actuator net) or "a1" (Unitree A1, PD law, on a plane).
 
 MODE "ref"  : the fork's anymal_c_flat config as committed (its reward is identically 0 after the
               positive clip: commands x,y are 0 so feet_air_time never pays).
@@ -19,6 +21,7 @@ import torch
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 hidden = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "128,64,32").split(",")]
 mode = sys.argv[3] if len(sys.argv) > 3 else "walk"
+robot = sys.argv[4] if len(sys.argv) > 4 else "anymal_c"
 
 from legged_gym_dev_amd.envs.anymal_c.anymal import Anymal
 from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
@@ -26,6 +29,13 @@ from legged_gym_dev_amd.rl.runner import OnPolicyRunner
 from legged_gym_dev_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
 
 env_cfg, train_cfg = AnymalCFlatCfg(), AnymalCFlatCfgPPO()
+EnvCls = Anymal
+if robot == "a1":
+    from legged_gym_dev_amd.envs.a1.a1_config import A1RoughCfg, A1RoughCfgPPO
+    from legged_gym_dev_amd.envs.base.legged_robot import LeggedRobot as EnvCls
+    env_cfg, train_cfg = A1RoughCfg(), A1RoughCfgPPO()
+    env_cfg.terrain.mesh_type, env_cfg.terrain.measure_heights, env_cfg.terrain.curriculum = "plane", False, False
+    env_cfg.env.num_observations = 48
 env_cfg.env.num_envs = 4096
 env_cfg.seed = 1
 if mode == "walk":
@@ -33,7 +43,8 @@ if mode == "walk":
     r.lin_vel_x, r.lin_vel_y, r.ang_vel_yaw = [-1.0, 1.0], [-1.0, 1.0], [-1.5, 1.5]
     sc = env_cfg.rewards.scales
     for k, v in dict(tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_vel_z=-2.0, ang_vel_xy=-0.05, dof_acc=-2.5e-7,
-                     collision=-1.0, action_rate=-0.01, orientation=-5.0, torques=-0.000025, feet_air_time=2.0).items():
+                     collision=-1.0, action_rate=-0.01, orientation=-5.0 if robot == "anymal_c" else -0.0,
+                     torques=-0.000025 if robot == "anymal_c" else -0.0002, feet_air_time=2.0 if robot == "anymal_c" else 1.0).items():
         setattr(sc, k, v)
 train_cfg.policy.actor_hidden_dims = list(hidden)
 train_cfg.policy.critic_hidden_dims = list(hidden)
@@ -41,7 +52,7 @@ args = get_args([])
 args.sim_device = args.rl_device = "cuda:0"
 torch.manual_seed(1)
 np.random.seed(1)
-env = Anymal(env_cfg, parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)}), args.physics_engine, "cuda:0", True)
+env = EnvCls(env_cfg, parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)}), args.physics_engine, "cuda:0", True)
 runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device="cuda:0")
 ppo = runner.ppo
 env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
