@@ -116,6 +116,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
                 memcpy(q, model->R_pj[d], 36); memcpy(q + 9, model->p_pj[d], 12); memcpy(q + 12, model->axis[d], 12);
                 memcpy(q + 15, model->inertia[d + 1], 36); memcpy(q + 24, model->com[d + 1], 12);
                 q[27] = model->mass[d + 1]; q[28] = model->joint_damping[d]; q[29] = model->vel_limit[d];
+                q[30] = model->q_lower[d]; q[31] = model->q_upper[d];
             }
             for (int s = 0; s < h.n_leg_slots; ++s) {
                 memcpy(t + LG_LT_SLOTS + 4 * s, h.slot_center[s][l], 12);

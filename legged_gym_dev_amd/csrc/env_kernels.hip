@@ -198,13 +198,14 @@ __global__ void __launch_bounds__(64, 1) k_physics(const DevParams *__restrict__
     __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
     __shared__ float s_lt[L * LG_LT_STRIDE];                // per-leg model constants: one coalesced copy per launch
+    __shared__ float s_lm[J * 4 * 64];                      // joint-limit constraint records
     for (int t = threadIdx.x; t < L * LG_LT_STRIDE; t += 64) s_lt[t] = (&P->leg_tab[0][0])[t];
     __syncthreads();
     const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
     for (int s = 0; s < ns; ++s) {
         V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-        const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt);
+        const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
         if (fault && live && leg == 0) P->fault[env] = 1;
         V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
         if (live) {
@@ -253,6 +254,7 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
     __shared__ float s_lt[L * LG_LT_STRIDE];
+    __shared__ float s_lm[J * 4 * 64];
     __shared__ float s_w[LSTM ? LG_LSTM_NW : 1];
     __shared__ float s_act[ROWS], s_q[ROWS], s_qd[ROWS], s_tau[ROWS];
     for (int t = tid; t < L * LG_LT_STRIDE; t += 256) s_lt[t] = (&P->leg_tab[0][0])[t];
@@ -342,7 +344,7 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
                 }
             for (int s = 0; s < ns; ++s) {
                 V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-                const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt);
+                const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
                 if (fault && live && leg == 0) P->fault[env] = 1;
                 V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
                 if (last && live) {

@@ -11,9 +11,10 @@
 #define LG_MAX_BASE_PER_LANE 2      // base collision spheres are dealt to the lanes of an env: sphere b -> lane b % L, slot b / L
 #define LG_NUM_SLOTS (LG_MAX_LEG_SLOTS + LG_MAX_BASE_PER_LANE)
 // per-leg constant table: joint j at LG_LT_JOINT*j: R_pj 0..8, p_pj 9..11, axis 12..14, child-link inertia 15..23,
-// com 24..26, mass 27, joint damping 28, velocity limit 29; then sphere slot s: centre 3 + radius; then the
+// com 24..26, mass 27, joint damping 28, velocity limit 29, position limits 30 (lower) 31 (upper); then sphere slot s:
+// centre 3 + radius; then the
 // base spheres of this lane (radius 0 = none).  Stride odd in 4-byte words: the L legs of a wave sit in different LDS banks.
-#define LG_LT_JOINT 30
+#define LG_LT_JOINT 32
 #define LG_LT_MAXJ 6
 #define LG_LT_SLOTS (LG_LT_JOINT * LG_LT_MAXJ)
 #define LG_LT_BASE (LG_LT_SLOTS + 4 * LG_MAX_LEG_SLOTS)

@@ -157,7 +157,7 @@ template <int L, int J>
 __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
                                              float *qd, const float *tau, float friction, float dmass,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt,
-                                             const float *__restrict__ ltab) {
+                                             const float *__restrict__ ltab, float *__restrict__ lmt) {
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
     const float *__restrict__ lt = ltab + leg * LG_LT_STRIDE;       // this leg's constants (LDS)
@@ -368,8 +368,53 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     const int n_leg_active = __popc(amask & ((1u << LG_MAX_LEG_SLOTS) - 1u));
     const float rl = __frcp_rn((float)max(n_leg_active, 1)), rb = __frcp_rn((float)max(n_base_active, 1));
 
-    // ---- projected Jacobi sweeps (wave-uniform trip counts; contact-free waves skip them)
-    if (__any(amask != 0u)) {
+    // ---- joint position limits (URDF lower / upper, equal = none) as unilateral constraints on the joint rate, active
+    // when the free motion would carry the joint past its stop within this step; W = response of the joint rate to a
+    // unit joint impulse through the same factors; records (sign, target rate, 1/W, impulse) in LDS columns
+#define LM(j, f) lmt[((j) * 4 + (f)) * 64 + lane]
+    unsigned lmask = 0u;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+        float sgn = 0.f, gap = 0.f;
+        if (hi > lo) {
+            const float qn = q[j] + dt * qdf[j];
+            if (qn > hi) { sgn = 1.0f; gap = hi - q[j]; }
+            else if (qn < lo) { sgn = -1.0f; gap = q[j] - lo; }
+        }
+        const bool act = sgn != 0.f;
+        if (!__any(act)) continue;                                   // wave-uniform: the usual case
+        Sv pAi = sv_zero();
+        float ui[J];
+#pragma unroll
+        for (int k = J - 1; k >= 0; --k) {
+            if (k > j) ui[k] = 0.f;
+            else {
+                ui[k] = (k == j ? 1.0f : 0.f) - sdot(S[k], pAi);
+                pAi = pAi + (ui[k] * iD[k]) * U[k];
+            }
+        }
+        Sv dv = -1.0f * mul6(I0inv, pAi);
+        float Wj = 0.f;
+#pragma unroll
+        for (int k = 0; k < J; ++k)
+            if (k <= j) {
+                const float dq = (ui[k] - sdot(U[k], dv)) * iD[k];
+                dv = dv + dq * S[k];
+                if (k == j) Wj = dq;
+            }
+        if (act) {
+            lmask |= 1u << j;
+            LM(j, 0) = sgn;
+            LM(j, 1) = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+            LM(j, 2) = Wj > 1e-9f ? __frcp_rn(Wj) : 0.f;
+            LM(j, 3) = 0.f;
+        }
+    }
+    const float rlim = __frcp_rn((float)max(__popc(lmask), 1));
+
+    // ---- projected Jacobi sweeps (wave-uniform trip counts; waves without contacts or active limits skip them)
+    if (__any((amask | lmask) != 0u)) {
         for (int it = 0; it < c.solver_iterations; ++it) {
             Sv fimp[J], fb = sv_zero();
 #pragma unroll
@@ -408,12 +453,22 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                         if (jl == k) fimp[k] = fimp[k] + f;
                 }
             }
-            float ui[J];
+            float ui[J], timp[J];
+#pragma unroll
+            for (int k = 0; k < J; ++k) {
+                timp[k] = 0.f;
+                if ((lmask >> k) & 1u) {
+                    const float sgn = LM(k, 0), old = LM(k, 3);
+                    const float ln = fmaxf(0.0f, old - rlim * (-sgn * qdf[k] - LM(k, 1)) * LM(k, 2));
+                    timp[k] = -sgn * (ln - old);
+                    LM(k, 3) = ln;
+                }
+            }
             Sv run = sv_zero();
 #pragma unroll
             for (int k = J - 1; k >= 0; --k) {
                 Sv cur = run - fimp[k];
-                ui[k] = -sdot(S[k], cur);
+                ui[k] = timp[k] - sdot(S[k], cur);
                 run = cur + (ui[k] * iD[k]) * U[k];
             }
             Sv pAi0 = leg_sum<L>(run - fb);
@@ -444,6 +499,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     }
 #undef CF
 #undef LK
+#undef LM
     // ---- fault guard (PhysX never hands back non-finite or absurd state; neither may we): an env whose
     // solve produced NaN/Inf or a base twist beyond 100 m/s | rad/s keeps its pose, is brought to rest and
     // is reported so that the post-step terminates and resets it.
@@ -462,6 +518,13 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         float v = qdf[j];
+        {   // hard stop behind the limit constraints: never end the step further out than max(limit, start)
+            const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+            if (hi > lo) {
+                const float qn = fminf(fmaxf(q[j] + dt * v, fminf(lo, q[j])), fmaxf(hi, q[j]));
+                v = (qn - q[j]) * inv_dt;
+            }
+        }
         float vl = lt[LG_LT_JOINT * j + 29];
         if (vl > 0.0f) v = fminf(fmaxf(v, -vl), vl);
         qd[j] = v;

@@ -214,12 +214,13 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     for (int d = 0; d < A; ++d) qdf[d] = dofs[2 * d + 1] + dt * qdd[d];
 
     // impulse propagation through the articulated-body factors: fimp = spatial impulse per link
-    auto propagate = [&](const Sv *fimp, Sv *dvel, float *dqd) {
+    // (timp: optional generalised impulse per joint, used by the joint-limit constraints)
+    auto propagate = [&](const Sv *fimp, Sv *dvel, float *dqd, const float *timp = nullptr) {
         Sv pAi[LG_MAX_DOF + 1];
         float ui[LG_MAX_DOF];
         for (int l = 0; l < NL; ++l) pAi[l] = -1.0f * fimp[l];
         for (int d = A - 1; d >= 0; --d) {
-            ui[d] = -sdot(S[d], pAi[d + 1]);
+            ui[d] = (timp ? timp[d] : 0.0f) - sdot(S[d], pAi[d + 1]);
             pAi[par[d]] = pAi[par[d]] + pAi[d + 1] + (ui[d] / D[d]) * U[d];
         }
         dvel[0] = -1.0f * mul(I0inv, pAi[0]);
@@ -269,9 +270,47 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     }
     for (int k = 0; k < nc; ++k) ct[k].relax = 1.0f / (float)group_count[ct[k].group];
 
+    // ---- joint position limits (URDF lower/upper; equal = none) as unilateral constraints on the joint rate:
+    // active when the free motion would carry the joint past the limit within this step.  gap rate = -sgn * qd must
+    // be >= vtarget (reach the limit exactly; when already beyond it, come back with the contacts' ERP and speed cap).
+    // W = response of qd to a unit joint impulse through the same articulated-body factors.
+    struct Limit { int d; float sgn, vtarget, iW, lam, relax; };
+    Limit lm[LG_MAX_DOF];
+    int nlim = 0;
+    int lim_count[LG_MAX_DOF + 1] = {};                                // active limits per leg chain (Jacobi relaxation, as for contacts)
+    for (int d = 0; d < A; ++d) {
+        const float lo = m.q_lower[d], hi = m.q_upper[d];
+        if (!(hi > lo)) continue;
+        const float q = dofs[2 * d];
+        float sgn = 0.0f, gap = 0.0f;
+        if (q + dt * qdf[d] > hi) { sgn = 1.0f; gap = hi - q; }
+        else if (q + dt * qdf[d] < lo) { sgn = -1.0f; gap = q - lo; }
+        if (sgn == 0.0f) continue;
+        float timp[LG_MAX_DOF] = {};
+        timp[d] = 1.0f;
+        Sv fz[LG_MAX_DOF + 1] = {};
+        Sv dv[LG_MAX_DOF + 1];
+        float dq[LG_MAX_DOF];
+        propagate(fz, dv, dq, timp);
+        Limit &Lm = lm[nlim++];
+        Lm.d = d; Lm.sgn = sgn; Lm.lam = 0.0f;
+        Lm.iW = dq[d] > 1e-9f ? 1.0f / dq[d] : 0.0f;
+        Lm.vtarget = gap >= 0.0f ? -gap / dt : std::min(-gap * c.contact_erp / dt, c.max_depenetration_velocity);
+        lim_count[d / m.joints_per_leg]++;
+    }
+    for (int k = 0; k < nlim; ++k) lm[k].relax = 1.0f / (float)lim_count[lm[k].d / m.joints_per_leg];
+
     // ---- projected Jacobi sweeps
-    for (int it = 0; it < c.solver_iterations && nc > 0; ++it) {
+    for (int it = 0; it < c.solver_iterations && nc + nlim > 0; ++it) {
         Sv fimp[LG_MAX_DOF + 1] = {};
+        float timp[LG_MAX_DOF] = {};
+        for (int k = 0; k < nlim; ++k) {
+            Limit &Lm = lm[k];
+            const float vc = -Lm.sgn * qdf[Lm.d];
+            const float ln = std::max(0.0f, Lm.lam - Lm.relax * (vc - Lm.vtarget) * Lm.iW);
+            timp[Lm.d] += -Lm.sgn * (ln - Lm.lam);
+            Lm.lam = ln;
+        }
         for (int k = 0; k < nc; ++k) {
             Contact &C = ct[k];
             V3 vP = velf[C.link].v + cross(velf[C.link].w, C.P);
@@ -292,7 +331,7 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
         }
         Sv dv[LG_MAX_DOF + 1];
         float dq[LG_MAX_DOF];
-        propagate(fimp, dv, dq);
+        propagate(fimp, dv, dq, timp);
         for (int l = 0; l < NL; ++l) velf[l] = velf[l] + dv[l];
         for (int d = 0; d < A; ++d) qdf[d] += dq[d];
     }
@@ -317,6 +356,13 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     }
     for (int d = 0; d < A; ++d) {
         float v = qdf[d];
+        if (m.q_upper[d] > m.q_lower[d]) {
+            // hard stop behind the limit constraints (a few Jacobi sweeps may leave a residual when several limits of one
+            // chain are active at once): the joint never ends the step further out than max(limit, where it started)
+            const float q0 = dofs[2 * d];
+            const float qn = std::min(std::max(q0 + dt * v, std::min(m.q_lower[d], q0)), std::max(m.q_upper[d], q0));
+            v = (qn - q0) / dt;
+        }
         if (m.vel_limit[d] > 0.0f) v = std::min(std::max(v, -m.vel_limit[d]), m.vel_limit[d]);
         dofs[2 * d + 1] = v;
         dofs[2 * d] += dt * v;

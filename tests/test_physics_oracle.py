@@ -136,6 +136,9 @@ def _random_state(env, cm, rng, n, z=5.0):
     root[:, 7:13] = rng.uniform(-1.5, 1.5, (n, 6))
     dof = np.zeros((n, A, 2), np.float32)
     dof[..., 0] = env.setup.default_dof_pos + rng.uniform(-0.5, 0.5, (n, A))
+    lo, hi = cm["q_lower"], cm["q_upper"]                      # free-flight tests: stay clear of the joint-limit constraints
+    lim = hi > lo
+    dof[..., 0] = np.where(lim, np.clip(dof[..., 0], lo + 0.05, hi - 0.05), dof[..., 0])
     dof[..., 1] = rng.uniform(-4, 4, (n, A))
     env.set("root_states", root)
     env.set("dof_state", dof)
@@ -241,5 +244,48 @@ def test_static_stance_supports_weight(robot, height, oracle_built):
             assert np.all(feet > 0.1 * weight / 4)
         else:                        # a PD-held biped is not statically stable: only sanity
             assert np.max(fz) > 0.5 * weight
+    finally:
+        env.close()
+
+
+@pytest.mark.parametrize("robot", ["a1", "cassie"])
+def test_joint_limits_hold_against_torque(robot, oracle_built):
+    """URDF joint limits are constraints of the solver.  Free flight, large torques: (env 0/1) every joint driven
+    into its upper / lower stop at once -- none ends a step beyond its stop (fp32 slack 2e-3 rad); (env 2) joints that
+    start 0.05 rad beyond the stop come back inside; (env 3) the last joint of every chain alone against its stop stays
+    pinned there while the torque lasts."""
+    env, cm, cfg = _make(robot, oracle_built, n=4)
+    try:
+        n, A, J = 4, cm["num_dofs"], cm["joints_per_leg"]
+        lo, hi = cm["q_lower"].astype(np.float64), cm["q_upper"].astype(np.float64)
+        assert np.all(hi > lo)
+        root = np.zeros((n, 13), np.float32)
+        root[:, 2] = 5.0
+        root[:, 6] = 1.0
+        dof = np.zeros((n, A, 2), np.float32)
+        mid = 0.5 * (lo + hi)
+        dof[..., 0] = mid
+        dof[0, :, 0] = hi - 0.01
+        dof[1, :, 0] = lo + 0.01
+        dof[2, :, 0] = hi + 0.05
+        last = np.arange(J - 1, A, J)
+        dof[3, last, 0] = hi[last] - 0.01
+        env.set("root_states", root)
+        env.set("dof_state", dof)
+        tmax = 3.0 if robot == "a1" else 20.0
+        tau = np.zeros((n, A), np.float32)
+        tau[0], tau[1] = tmax, -tmax
+        tau[3, last] = tmax
+        env.set("torques", tau)
+        worst_hi, worst_lo = -1.0, -1.0
+        for _ in range(40):
+            env.call("simulate")
+            d = env.get("dof_state").astype(np.float64)
+            worst_hi = max(worst_hi, float(np.max(d[0, :, 0] - hi)), float(np.max(d[3, last, 0] - hi[last])))
+            worst_lo = max(worst_lo, float(np.max(lo - d[1, :, 0])))
+        assert np.all(np.isfinite(d))
+        assert worst_hi <= 2e-3 and worst_lo <= 2e-3, (worst_hi, worst_lo)
+        assert np.all(d[2, :, 0] <= hi + 0.02), (d[2, :, 0] - hi)         # ERP 0.2 per step for 40 steps: back inside
+        assert np.all(np.abs(d[3, last, 0] - hi[last]) < 0.03) and np.all(np.abs(d[3, last, 1]) < 0.5)
     finally:
         env.close()
