@@ -3,15 +3,16 @@
 // Replaces gym.simulate() (reference call site legged_gym/envs/base/legged_robot.py:92-96).  The
 // algorithm is the build's own specification (oracle/lgo_physics.cpp restates it scalar, generic
 // tree): Featherstone ABA in base-frame coordinates about the base origin, exact 3x3 contact-space
-// inverse inertia per sphere contact from test impulses, projected-Jacobi contact sweeps, one tree
-// impulse propagation per sweep, semi-implicit Euler.
+// inverse inertia per sphere contact from test impulses, projected-Jacobi sweeps over contacts and
+// joint-limit constraints, one tree impulse propagation per sweep, semi-implicit Euler.
 //
 // Mapping to CDNA4: a wave64 holds 64/L environments; the L lanes of an environment own one leg
-// chain each (J revolute joints, fully unrolled so every per-joint quantity stays in VGPRs), and
-// meet only at the floating base through L-lane butterfly sums (ds_swizzle / DPP via __shfl_xor):
-// 27 floats for the articulated base inertia + bias, 6 floats per contact sweep.  No LDS, no
-// barriers, no divergence between legs; contact slots are skipped wave-uniformly (__any) when no
-// lane of the wave has that sphere near the ground.
+// chain each (J revolute joints, unrolled; S, U, 1/D, u and the base inverse inertia in VGPRs), and
+// meet only at the floating base through L-lane butterfly sums (DPP via __shfl_xor): 27 floats for
+// the articulated base inertia + bias, 6 floats per sweep.  Per-leg model constants, per-link tiles,
+// contact-slot and joint-limit records live in LDS columns (field-major, one column per lane:
+// conflict-free).  No barriers inside a step, no divergence between legs; contact work walks each
+// lane's own list of active slots, limit work is skipped wave-uniformly when no lane needs it.
 #pragma once
 #include "lg_device.h"
 

@@ -18,6 +18,9 @@
 //      normal row, then the two friction rows; Coulomb disc |lt| <= mu ln; speculative margin for
 //      open gaps, ERP-limited depenetration capped at max_depenetration_velocity), each sweep followed
 //      by ONE impulse propagation through the tree; relaxation 1/(active contacts in the same chain);
+//   4b. URDF joint position limits ride in the same sweeps as unilateral constraints on the joint rate (active when the
+//      free motion would pass the stop within the step; W from a unit joint impulse; relaxation 1/(active limits in the
+//      chain)), with a hard stop at integration: a step never ends further out than max(limit, start);
 //   5. semi-implicit Euler: positions advance with the post-contact velocities; net contact force per
 //      body = sum of its spheres' impulses / dt, world frame.
 #include "lgo_common.h"
