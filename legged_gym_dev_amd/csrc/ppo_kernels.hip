@@ -737,6 +737,25 @@ __global__ void k_gather(PpoDev P, int mb) {
     }
 }
 
+// same gather, 32 lanes per row moving 16 bytes each (obs, actions, mu as float4s; the four scalars as one float4):
+// used when O, OC and A are multiples of 4 (every pointer is then 16-byte aligned row by row)
+__global__ void __launch_bounds__(256) k_gather4(PpoDev P, int mb) {
+    const int R = P.mb_rows, A4 = P.A / 4, O4 = P.O / 4;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int r = gid >> 5, j = gid & 31;
+    if (r >= R) return;
+    const int src = P.perm[(size_t)mb * R + r];
+    const bool own_critic = P.st_critic_obs != P.st_obs;
+    const int OC4 = own_critic ? P.OC / 4 : 0;
+    for (int k = j; k < O4 + OC4 + 2 * A4 + 1; k += 32) {
+        if (k < O4) reinterpret_cast<float4 *>(P.mb_obs)[(size_t)r * O4 + k] = reinterpret_cast<const float4 *>(P.st_obs)[(size_t)src * O4 + k];
+        else if (k < O4 + OC4) reinterpret_cast<float4 *>(P.mb_critic_obs)[(size_t)r * OC4 + (k - O4)] = reinterpret_cast<const float4 *>(P.st_critic_obs)[(size_t)src * OC4 + (k - O4)];
+        else if (k < O4 + OC4 + A4) reinterpret_cast<float4 *>(P.mb_actions)[(size_t)r * A4 + (k - O4 - OC4)] = reinterpret_cast<const float4 *>(P.st_actions)[(size_t)src * A4 + (k - O4 - OC4)];
+        else if (k < O4 + OC4 + 2 * A4) reinterpret_cast<float4 *>(P.mb_mu)[(size_t)r * A4 + (k - O4 - OC4 - A4)] = reinterpret_cast<const float4 *>(P.st_mu)[(size_t)src * A4 + (k - O4 - OC4 - A4)];
+        else reinterpret_cast<float4 *>(P.mb_scalars)[r] = make_float4(P.st_values[src], P.st_returns[src], P.st_adv[src], P.st_log_prob[src]);
+    }
+}
+
 // PPO.update loss for one minibatch: surrogate, clipped value loss, entropy bonus, KL(old || new);
 // emits d loss / d mu (R x A), d loss / d value (R), and block-reduced d loss / d std, bias grads
 // of both heads and the loss statistics.
@@ -751,6 +770,14 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
     float part[2 * MA + 4];
 #pragma unroll
     for (int k = 0; k < 2 * MA + 4; ++k) part[k] = 0.f;
+    // the two logarithms of every action dimension depend on sigma only: once per block instead of once per row
+    __shared__ float s_logs[MA], s_logr[MA];
+    if ((int)threadIdx.x < A) {
+        const float s = std[threadIdx.x], so = P.st_sigma[threadIdx.x];
+        s_logs[threadIdx.x] = logf(s);
+        s_logr[threadIdx.x] = logf(s / so + 1.e-5f);
+    }
+    __syncthreads();
     if (r < R) {
         const float4 sc = reinterpret_cast<const float4 *>(P.mb_scalars)[r];
         const float v_old = sc.x, ret = sc.y, adv = sc.z, lp_old = sc.w;
@@ -763,8 +790,8 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
                 const float m = mu_new[(size_t)r * A + a], mo = P.mb_mu[(size_t)r * A + a];
                 const float d = P.mb_actions[(size_t)r * A + a] - m;
                 dd[a] = d;
-                lp += -(d * d) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
-                kl += logf(s / so + 1.e-5f) + (so * so + (mo - m) * (mo - m)) / (2.0f * s * s) - 0.5f;
+                lp += -(d * d) / (2.0f * s * s) - s_logs[a] - 0.9189385332046727f;
+                kl += s_logr[a] + (so * so + (mo - m) * (mo - m)) / (2.0f * s * s) - 0.5f;
             }
         }
         const float ratio = expf(lp - lp_old);
@@ -1146,7 +1173,10 @@ void ppok_adv_normalize(const PpoDev *P, hipStream_t s) {
     hipLaunchKernelGGL(k_adv_normalize, dim3(256), dim3(256), 0, s, *P);
 }
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather, dim3(P->mb_rows), dim3(64), 0, s, *P, mb);
+    if ((P->O & 3) == 0 && (P->A & 3) == 0 && (P->OC & 3) == 0)
+        hipLaunchKernelGGL(k_gather4, dim3((P->mb_rows * 32 + 255) / 256), dim3(256), 0, s, *P, mb);
+    else
+        hipLaunchKernelGGL(k_gather, dim3(P->mb_rows), dim3(64), 0, s, *P, mb);
 }
 // returns 0 when the fused head kernel supports this width, -1 otherwise (caller falls back to GEMMs + k_loss)
 int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
