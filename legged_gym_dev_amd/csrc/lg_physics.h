@@ -287,7 +287,8 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     unsigned long long link_pk = 0ull;
     for (int s = 0; s < nslots; ++s) link_pk |= (unsigned long long)(P->slot_link[s] & 15) << (4 * s);
     // (1) detection over every slot: geometry only
-    for (int s = 0; s < nslots + LG_MAX_BASE_PER_LANE; ++s) {
+    const int nbase_it = (P->n_base_spheres + L - 1) / L;       // base spheres per lane this robot needs (wave-uniform)
+    for (int s = 0; s < nslots + nbase_it; ++s) {
         const bool is_base = s >= nslots;
         const int ub = s - nslots;                              // which of this lane's base spheres
         const int si = is_base ? LG_MAX_LEG_SLOTS + ub : s;

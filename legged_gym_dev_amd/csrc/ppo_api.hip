@@ -128,7 +128,6 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         }
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * act'(act[l]); db_{l-1} = colsum(dz[l])
             memset(&g, 0, sizeof(g));
-            int ldb_pl[2] = {0, 0};
             for (int z = 0; z < 2; ++z) {
                 Net &n = p->net[z];
                 g.A[z] = n.dz[l + 1]; g.lda[z] = n.dims[l + 1];
@@ -137,12 +136,9 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
                 g.aux[z] = n.act[l]; g.ldaux[z] = n.dims[l];
                 g.colsum[z] = p->dev.grads + n.b_off[l - 1];
                 g.M[z] = M; g.N[z] = n.dims[l]; g.K[z] = n.dims[l + 1];
-                g.Bpl[z] = p->dev.wtpl + n.pl_off[l];            // W^T [k'][n]: reduction-contiguous rows of length dims[l+1]
-                ldb_pl[z] = n.dims[l + 1];
             }
-            g.pl_stride = p->dev.pl_stride;
             g.elu = p->act_code;                         // derivative of the hidden activation, through its output act[l]
-            ppok_gemm_dx(&g, 2, ldb_pl, p->stream);
+            ppok_gemm_dx(&g, 2, nullptr, p->stream);
         }
     }
     if (p->overlap) {                                // join: the optimiser step (main stream) needs every dW
@@ -233,7 +229,12 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     PA(d.params, off + 2); PA(d.grads, off + 2); PA(d.adam_m, off + 2); PA(d.adam_v, off + 2);
     {
         const int64_t pls = d.pl_stride;            // PA memsets through d.*: keep the stride across the allocation macros
-        PA(d.wpl, (size_t)3 * pls + 8); PA(d.wtpl, (size_t)3 * pls + 8);
+        PA(d.wpl, (size_t)3 * pls + 8);
+        PA(d.pl_dest, (size_t)off + 2);
+        std::vector<int32_t> dest((size_t)off + 2, -1);
+        for (int sg = 0; sg < d.nseg; ++sg)
+            for (int64_t e = 0; e < (int64_t)d.seg_rows[sg] * d.seg_cols[sg]; ++e) dest[d.seg_off[sg] + e] = (int32_t)(d.seg_pl[sg] + e);
+        (void)hipMemcpy(d.pl_dest, dest.data(), dest.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
     const size_t TN = (size_t)T * N;
     PA(d.st_obs, TN * O);

@@ -35,9 +35,10 @@ struct PpoDev {                    // passed by value to kernels
     float *adv_partial;
     float *mb_obs, *mb_critic_obs, *mb_actions, *mb_mu, *mb_scalars;   // minibatch gathers; scalars = [v_old, ret, adv, logp_old]
     float *cur_reward_sum, *cur_episode_len, *ep_stats;                // per-env running sums; [sum_rew, sum_len, count] of finished episodes
-    // split-bf16 images of the weight matrices, maintained by the optimiser step: wpl = W [n][k], wtpl = W^T [k][n];
-    // three planes (h, m, l) pl_stride elements apart; segment s = one weight matrix (rows x cols at flat offset seg_off)
-    uint16_t *wpl, *wtpl;
+    // split-bf16 image of the weight matrices W [n][k], maintained by the optimiser step: three planes (h, m, l)
+    // pl_stride elements apart; segment s = one weight matrix (rows x cols at flat offset seg_off)
+    uint16_t *wpl;
+    int32_t *pl_dest;              // per parameter: element index inside a plane, -1 for parameters that are not weights
     int64_t pl_stride;
     int nseg;
     int64_t seg_off[LG_PPO_MAX_SEG], seg_pl[LG_PPO_MAX_SEG];

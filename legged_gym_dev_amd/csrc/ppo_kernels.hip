@@ -395,6 +395,88 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     }
 }
 
+// Epilogue of k_gemm.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  ACT: 1 = ELU and 0 = none are
+// compiled in (the reference's configurations); -1 = the activation code g.elu is switched on per element.
+template <int EPI, int TM, int TN, int BM, int BN, int ACT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, int N, int m0, int n0, int wm, int wn, int li, int lk, int ldc,
+                                              f32x16 (&acc)[TM][TN]) {
+    float *__restrict__ C = g.C[z];
+    const bool interior = (m0 + BM <= M) && (n0 + BN <= N);     // workgroup-uniform
+    const int elu = g.elu;                                      // activation code (workgroup-uniform)
+    if (interior) {
+        // unguarded path: loads of the epilogue operand are issued as one batch (no per-element branch,
+        // which would serialise them behind s_waitcnt vmcnt(0)), then compute + store
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int n = n0 + wn + 32 * b + li;
+            float csum = 0.f;
+            const float bias = (EPI == 0 && g.bias[z]) ? g.bias[z][n] : 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int mb = m0 + wm + 32 * a + 4 * lk;
+                float aux[16];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        aux[r] = g.aux[z][(size_t)(mb + (r & 3) + 8 * (r >> 2)) * g.ldaux[z] + n];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *cp = &C[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * ldc + n];
+                    float v = acc[a][b][r];
+                    if (EPI == 0) {
+                        v += bias;
+                        v = (ACT == 1 ? (v > 0.f ? v : __expf(v) - 1.0f) : ACT == 0 ? v : act_fwd(elu, v));
+                        *cp = v;
+                    } else if (EPI == 1) {
+                        v *= (ACT == 1 ? (aux[r] > 0.f ? 1.0f : aux[r] + 1.0f) : ACT == 0 ? 1.0f : act_bwd(elu, aux[r]));
+                        *cp = v;
+                        csum += v;
+                    } else {
+                        atomicAdd(cp, v);
+                    }
+                }
+            }
+            if (EPI == 1 && g.colsum[z]) {
+                csum += __shfl_xor(csum, 32);
+                if (lk == 0) atomicAdd(&g.colsum[z][n], csum);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn + 32 * b + li;
+        float csum = 0.f;
+        const float bias = (EPI == 0 && g.bias[z] && n < N) ? g.bias[z][n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < M && n < N) {
+                    float v = acc[a][b][r];
+                    if (EPI == 0) {
+                        v += bias;
+                        v = (ACT == 1 ? (v > 0.f ? v : __expf(v) - 1.0f) : ACT == 0 ? v : act_fwd(elu, v));
+                        C[(size_t)m * ldc + n] = v;
+                    } else if (EPI == 1) {
+                        const float act = g.aux[z][(size_t)m * g.ldaux[z] + n];
+                        v *= (ACT == 1 ? (act > 0.f ? 1.0f : act + 1.0f) : ACT == 0 ? 1.0f : act_bwd(elu, act));
+                        C[(size_t)m * ldc + n] = v;
+                        csum += v;
+                    } else {
+                        atomicAdd(&C[(size_t)m * ldc + n], v);
+                    }
+                }
+            }
+        if (EPI == 1 && g.colsum[z]) {
+            csum += __shfl_xor(csum, 32);
+            if (lk == 0 && n < N) atomicAdd(&g.colsum[z][n], csum);
+        }
+    }
+}
+
 template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, bool B_PL = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) : 1) k_gemm(GemmArgs g) {
     static_assert(!B_PL || (X6 && B_RC), "weight planes feed the split-bf16 mainloop as a reduction-contiguous operand");
@@ -454,82 +536,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
         else gemm_mainloop<A_RC, B_RC, TM, TN, false, DBUF>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds, wm, wn, li, lk, acc);
     }
 
-    // ---- epilogue.  acc[a][b][r]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *__restrict__ C = g.C[z];
-    const bool interior = (m0 + BM <= M) && (n0 + BN <= N);     // workgroup-uniform
-    const int elu = g.elu;                                      // activation code (workgroup-uniform)
-    if (interior) {
-        // unguarded path: loads of the epilogue operand are issued as one batch (no per-element branch,
-        // which would serialise them behind s_waitcnt vmcnt(0)), then compute + store
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int n = n0 + wn + 32 * b + li;
-            float csum = 0.f;
-            const float bias = (EPI == 0 && g.bias[z]) ? g.bias[z][n] : 0.f;
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int mb = m0 + wm + 32 * a + 4 * lk;
-                float aux[16];
-                if (EPI == 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        aux[r] = g.aux[z][(size_t)(mb + (r & 3) + 8 * (r >> 2)) * g.ldaux[z] + n];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float *cp = &C[(size_t)(mb + (r & 3) + 8 * (r >> 2)) * ldc + n];
-                    float v = acc[a][b][r];
-                    if (EPI == 0) {
-                        v += bias;
-                        v = act_fwd(elu, v);
-                        *cp = v;
-                    } else if (EPI == 1) {
-                        v *= act_bwd(elu, aux[r]);
-                        *cp = v;
-                        csum += v;
-                    } else {
-                        atomicAdd(cp, v);
-                    }
-                }
-            }
-            if (EPI == 1 && g.colsum[z]) {
-                csum += __shfl_xor(csum, 32);
-                if (lk == 0) atomicAdd(&g.colsum[z][n], csum);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn + 32 * b + li;
-        float csum = 0.f;
-        const float bias = (EPI == 0 && g.bias[z] && n < N) ? g.bias[z][n] : 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < M && n < N) {
-                    float v = acc[a][b][r];
-                    if (EPI == 0) {
-                        v += bias;
-                        v = act_fwd(elu, v);
-                        C[(size_t)m * ldc + n] = v;
-                    } else if (EPI == 1) {
-                        const float act = g.aux[z][(size_t)m * g.ldaux[z] + n];
-                        v *= act_bwd(elu, act);
-                        C[(size_t)m * ldc + n] = v;
-                        csum += v;
-                    } else {
-                        atomicAdd(&C[(size_t)m * ldc + n], v);
-                    }
-                }
-            }
-        if (EPI == 1 && g.colsum[z]) {
-            csum += __shfl_xor(csum, 32);
-            if (lk == 0 && n < N) atomicAdd(&g.colsum[z][n], csum);
-        }
-    }
+    // ---- epilogue (activation specialised on the workgroup-uniform code)
+    if (EPI == 2 || g.elu == 1) gemm_epilogue<EPI, TM, TN, BM, BN, 1>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
+    else if (g.elu == 0) gemm_epilogue<EPI, TM, TN, BM, BN, 0>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
+    else gemm_epilogue<EPI, TM, TN, BM, BN, -1>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
 }
 
 static int g_gemm_dbuf = 0;   // single LDS buffer (34 KB, 4 workgroups/CU) measured 3-15 % faster than double buffering
@@ -542,7 +552,8 @@ static int g_gemm_planes = 1;  // forward / input-gradient GEMMs take the weight
 extern "C" void ppok_debug_set_planes(int v) { g_gemm_planes = v; }
 
 // forward (EPI 0) and input gradient (EPI 1) with B = pre-split weight planes, reduction-contiguous
-static int g_gemm_t96 = 1;     // allow the 96x128 tile when it fills the chip's 512 workgroup slots in fewer, or fuller, rounds
+static int g_gemm_t96 = 0;     // 96x128 tile where it fills the 512 workgroup slots in fuller rounds: measured slower end to end
+                               // (the side stream's weight-gradient GEMMs already fill the idle slots); kept for A/B
 extern "C" void ppok_debug_set_t96(int v) { g_gemm_t96 = v; }
 
 template <int EPI>
@@ -592,8 +603,9 @@ static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
         else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, true>), grid, dim3(256), 0, s, g);
     }
 }
-// g->Bpl (optional): planes of W [n][k] for the forward; for the input gradient planes of W^T [k'][n] with ldb = n --
-// the caller passes both B (fp32 W, layout of the plain path) and Bpl; whichever path is eligible is taken
+// g->Bpl (optional): bf16 planes of W [n][k]; the caller passes both B (fp32 W) and Bpl, whichever path is eligible is
+// taken.  (Planes of W^T for the input gradient were measured too: the scattered 2-byte stores that keep them current in
+// the optimiser kernel cost what they saved in the GEMM; ppok_gemm_dx keeps the hook, the caller passes none.)
 extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) {
     if (planes_ok(*g, nz)) launch_gemm_pl<0>(*g, nz, s);
     else launch_gemm<true, true, 0>(*g, nz, 1, s);
@@ -1113,20 +1125,13 @@ __global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par) {
     }
     if (threadIdx.x == 0) atomicAdd(&P.loss_acc[2 + par], red[0]);
 }
-// split-bf16 images of parameter k (if it belongs to a weight matrix): W plane at [n][c], W^T plane at [c][n]
+// split-bf16 image of parameter k: pl_dest[k] = its element index inside a plane (weights) or -1 (biases, std)
 __device__ __forceinline__ void write_planes(const PpoDev &P, int64_t k, float x) {
-    for (int s = 0; s < P.nseg; ++s) {
-        const int64_t rel = k - P.seg_off[s];
-        if (rel >= 0 && rel < (int64_t)P.seg_rows[s] * P.seg_cols[s]) {
-            const int n = (int)(rel / P.seg_cols[s]), c = (int)(rel % P.seg_cols[s]);
-            uint32_t h, m, l;
-            split2(x, 0.f, h, m, l);
-            const int64_t a = P.seg_pl[s] + rel, t = P.seg_pl[s] + (int64_t)c * P.seg_rows[s] + n;
-            P.wpl[a] = (uint16_t)h; P.wpl[P.pl_stride + a] = (uint16_t)m; P.wpl[2 * P.pl_stride + a] = (uint16_t)l;
-            P.wtpl[t] = (uint16_t)h; P.wtpl[P.pl_stride + t] = (uint16_t)m; P.wtpl[2 * P.pl_stride + t] = (uint16_t)l;
-            return;
-        }
-    }
+    const int d = P.pl_dest[k];
+    if (d < 0) return;
+    uint32_t h, m, l;
+    split2(x, 0.f, h, m, l);
+    P.wpl[d] = (uint16_t)h; P.wpl[P.pl_stride + d] = (uint16_t)m; P.wpl[2 * P.pl_stride + d] = (uint16_t)l;
 }
 // rebuild every plane from the fp32 parameters (begin of an update: parameters may have been written through
 // the zero-copy views -- checkpoint load, initial broadcast)
