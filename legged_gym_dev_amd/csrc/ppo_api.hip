@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "ppo_device.h"
+#include "ppo_mlp_args.h"
 
 void lg_set_error(const std::string &s);
 
@@ -12,6 +13,7 @@ extern "C" {
 void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s);
 void ppok_gemm_dx(const GemmArgs *g, int nz, const int *ldb_planes, hipStream_t s);
 void ppok_sync_planes(const PpoDev *P, hipStream_t s);
+int ppok_mlp_fwd(const MlpArgs *g, int mask, hipStream_t s);
 void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s);
 void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
                      int64_t cnt, int inject, hipStream_t s);
@@ -43,7 +45,8 @@ struct lg_ppo {
     hipEvent_t ev_dz, ev_side;
     int overlap;
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
-    int grads_dirty;                         // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
+    int grads_dirty;
+    int fused_act;                           // rollout forward through k_mlp_fwd when the network shape allows (else per-layer GEMMs)                         // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
     int step, inject;
     int64_t act_count, update_count;
     int Mmax;
@@ -174,6 +177,11 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->cfg = *cfg;
     p->stream = nullptr;
     p->act_code = cfg->activation + 1;
+    // the one-launch rollout forward (ppo_mlp_fused.hip) is one wave per SIMD by its LDS footprint: measured 29 vs 35 us per
+    // act() for [128,64,32] but 68 vs 61 us for [512,256,128], where the per-layer GEMMs' four waves per SIMD win
+    p->fused_act = 1;
+    for (int l = 0; l < cfg->num_hidden; ++l)
+        if (cfg->actor_hidden[l] > 128 || cfg->critic_hidden[l] > 128) p->fused_act = 0;
     p->overlap = 1;
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
@@ -278,6 +286,7 @@ int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out) { *out = p->pub; return 0
 int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0; }
 int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
 int lg_ppo_debug_set_overlap(lg_ppo *p, int v) { p->overlap = v; return 0; }
+int lg_ppo_debug_set_fused_act(lg_ppo *p, int v) { p->fused_act = v; return 0; }
 
 // entries: std, then per net per layer (W, b).  offsets[i]; shapes[2i] = rows, shapes[2i+1] = cols (0 for vectors)
 int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_entries) {
@@ -298,7 +307,26 @@ int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_en
 int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
     if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
     const float *cobs = critic_obs ? critic_obs : obs;
-    forward(p, p->cfg.num_envs, obs, cobs, 3);
+    int fused = -1;
+    if (p->fused_act) {
+        // the weight planes follow the parameters inside an update; anything else (load, broadcast) may have
+        // written the fp32 buffer in between, so the first act of a rollout rebuilds them
+        if (p->step == 0) ppok_sync_planes(&p->dev, p->stream);
+        MlpArgs g;
+        memset(&g, 0, sizeof(g));
+        g.in[0] = obs; g.in[1] = cobs;
+        g.params = p->dev.params; g.wpl = p->dev.wpl; g.pl_stride = p->dev.pl_stride;
+        g.M = p->cfg.num_envs; g.nl = p->net[0].nl; g.act = p->act_code;
+        bool same = p->net[0].nl == p->net[1].nl;
+        for (int z = 0; z < 2 && same; ++z) {
+            Net &n = p->net[z];
+            g.out[z] = n.act[n.nl];
+            for (int l = 0; l <= n.nl; ++l) g.dims[z][l] = n.dims[l];
+            for (int l = 0; l < n.nl; ++l) { g.pl_off[z][l] = n.pl_off[l]; g.b_off[z][l] = n.b_off[l]; }
+        }
+        if (same) fused = ppok_mlp_fwd(&g, 3, p->stream);
+    }
+    if (fused != 0) forward(p, p->cfg.num_envs, obs, cobs, 3);
     ppok_act_sample(&p->dev, obs, cobs, p->net[0].act[p->net[0].nl], p->net[1].act[p->net[1].nl], p->step, p->act_count,
                     p->inject, p->stream);
     p->act_count++;

@@ -1,0 +1,14 @@
+// Arguments of the fused rollout forward (ppo_mlp_fused.hip), shared with the C-ABI layer.
+#pragma once
+#include "ppo_device.h"
+
+struct MlpArgs {
+    const float *in[2];            // [M][dims[z][0]] observations of net z
+    float *out[2];                 // [M][dims[z][nl]] head outputs
+    const float *params;           // fp32 parameters (biases)
+    const uint16_t *wpl;           // weight planes
+    int64_t pl_stride;
+    int M, nl, act;                // rows, linear layers, activation code of the hidden layers (as k_gemm)
+    int dims[2][LG_PPO_MAX_LAYERS + 1];
+    int64_t pl_off[2][LG_PPO_MAX_LAYERS], b_off[2][LG_PPO_MAX_LAYERS];
+};

@@ -24,7 +24,10 @@ timeit("env.core.step", lambda: env.core.step(a))
 timeit("env.step (python shim)", lambda: env.step(a))
 def act():
     ppo._call("end_update"); ppo.act(obs, None)
-timeit("ppo.act", act)
+timeit("ppo.act (fused forward)", act)
+ppo.lib.lg_ppo_debug_set_fused_act(ppo.ctx, 0)
+timeit("ppo.act (per-layer GEMMs)", act)
+ppo.lib.lg_ppo_debug_set_fused_act(ppo.ctx, 1)
 def proc():
     ppo._call("end_update"); ppo.process_env_step(env.rew_buf, env.core.t["reset"], {"time_outs": env.core.t["extras_time_outs"]})
 timeit("ppo.process_env_step", proc)
