@@ -1,54 +1,46 @@
-"""ANYmal-C on mixed terrain (reference: envs/anymal_c/mixed_terrains/anymal_c_rough_config.py:33-94)."""
+"""ANYmal-C on mixed terrain (reference: envs/anymal_c/mixed_terrains/anymal_c_rough_config.py:33-94).
+
+Declared as a tree (envs/base/base_config.py: cfg_class / S): each S(...) becomes the nested section class a
+hand-written ``class <section>(Base.<section>)`` would be, so tasks still override by subclassing.
+"""
+from legged_gym_dev_amd.envs.base.base_config import S, cfg_class
 from legged_gym_dev_amd.envs.base.legged_robot_config import LeggedRobotCfg, LeggedRobotCfgPPO
 
 
-class AnymalCRoughCfg(LeggedRobotCfg):
-    class env(LeggedRobotCfg.env):
-        num_envs = 4096
-        num_actions = 12
+AnymalCRoughCfg = cfg_class("AnymalCRoughCfg", LeggedRobotCfg, dict(
+    env=S(
+        num_envs=4096, num_actions=12,
+    ),
+    terrain=S(
+        mesh_type='trimesh',
+    ),
+    init_state=S(
+        pos=[0.0, 0.0, 0.6],
+        default_joint_angles={'LF_HAA': 0.0, 'LH_HAA': 0.0, 'RF_HAA': -0.0, 'RH_HAA': -0.0, 'LF_HFE': 0.4, 'LH_HFE': -0.4, 'RF_HFE': 0.4, 'RH_HFE': -0.4, 'LF_KFE': -0.8, 'LH_KFE': 0.8, 'RF_KFE': -0.8, 'RH_KFE': 0.8},
+    ),
+    control=S(
+        stiffness={'HAA': 80.0, 'HFE': 80.0, 'KFE': 80.0}, damping={'HAA': 2.0, 'HFE': 2.0, 'KFE': 2.0},
+        action_scale=0.5, decimation=4, use_actuator_network=True,
+        actuator_net_file='{LEGGED_GYM_ROOT_DIR}/resources/actuator_nets/anydrive_v3_lstm.pt',
+    ),
+    asset=S(
+        file='{LEGGED_GYM_ROOT_DIR}/resources/robots/anymal_c/urdf/anymal_c.urdf', name='anymal_c',
+        foot_name='FOOT', penalize_contacts_on=['SHANK', 'THIGH'], terminate_after_contacts_on=['base'],
+        self_collisions=1,
+    ),
+    domain_rand=S(
+        randomize_base_mass=True, added_mass_range=[-5.0, 5.0],
+    ),
+    rewards=S(
+        base_height_target=0.5, max_contact_force=500.0, only_positive_rewards=True,
+        scales=S(
 
-    class terrain(LeggedRobotCfg.terrain):
-        mesh_type = "trimesh"
+        ),
+    ),
+), doc=None, module=__name__)
 
-    class init_state(LeggedRobotCfg.init_state):
-        pos = [0.0, 0.0, 0.6]
-        default_joint_angles = {
-            "LF_HAA": 0.0, "LH_HAA": 0.0, "RF_HAA": -0.0, "RH_HAA": -0.0,
-            "LF_HFE": 0.4, "LH_HFE": -0.4, "RF_HFE": 0.4, "RH_HFE": -0.4,
-            "LF_KFE": -0.8, "LH_KFE": 0.8, "RF_KFE": -0.8, "RH_KFE": 0.8,
-        }
-
-    class control(LeggedRobotCfg.control):
-        stiffness = {"HAA": 80.0, "HFE": 80.0, "KFE": 80.0}
-        damping = {"HAA": 2.0, "HFE": 2.0, "KFE": 2.0}
-        action_scale = 0.5
-        decimation = 4
-        use_actuator_network = True
-        actuator_net_file = "{LEGGED_GYM_ROOT_DIR}/resources/actuator_nets/anydrive_v3_lstm.pt"
-
-    class asset(LeggedRobotCfg.asset):
-        file = "{LEGGED_GYM_ROOT_DIR}/resources/robots/anymal_c/urdf/anymal_c.urdf"
-        name = "anymal_c"
-        foot_name = "FOOT"
-        penalize_contacts_on = ["SHANK", "THIGH"]
-        terminate_after_contacts_on = ["base"]
-        self_collisions = 1
-
-    class domain_rand(LeggedRobotCfg.domain_rand):
-        randomize_base_mass = True
-        added_mass_range = [-5.0, 5.0]
-
-    class rewards(LeggedRobotCfg.rewards):
-        base_height_target = 0.5
-        max_contact_force = 500.0
-        only_positive_rewards = True
-
-        class scales(LeggedRobotCfg.rewards.scales):
-            pass
-
-
-class AnymalCRoughCfgPPO(LeggedRobotCfgPPO):
-    class runner(LeggedRobotCfgPPO.runner):
-        run_name = ""
-        experiment_name = "rough_anymal_c"
-        load_run = -1
+AnymalCRoughCfgPPO = cfg_class("AnymalCRoughCfgPPO", LeggedRobotCfgPPO, dict(
+    runner=S(
+        run_name='', experiment_name='rough_anymal_c', load_run=-1,
+    ),
+), doc=None, module=__name__)
