@@ -1,0 +1,73 @@
+"""profiles/rNN_README.md from the digested files of a round (run after tools/digest_profiles.py)."""
+import json, os, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pr = os.path.join(root, "profiles")
+tab = open(os.path.join(pr, f"{tag}_kernel_table.md")).read()
+tr = json.load(open(os.path.join(pr, f"{tag}_pmc_traffic.json")))
+b = json.loads(open(os.path.join(pr, f"{tag}_bench_n1.json")).read())
+r = b["roofline"]
+tests = open(os.path.join(pr, f"{tag}_gpu_tests.log")).read().strip().splitlines()[-1]
+txt = f"""# Round {int(tag[1:])} profiles (MI355X, rocprofv3)
+
+All from one build, collected by
+
+```
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/{tag}_prof -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_alt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/{tag}_pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_alt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/{tag}_pmc_write -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_alt
+python tools/digest_profiles.py {tag} && python tools/write_profile_readme.py {tag}
+```
+
+Workload: anymal_c_flat, 4096 envs, ActorCritic [512,256,128] (BASELINE.json configs[1]).
+
+| file | content |
+|---|---|
+| `{tag}_bench_n1.json` | the un-profiled `python bench.py` line of this build: **{b['value']:,.0f} env-steps/s**, {b['ms_per_step']} ms per PPO iteration (rollout {b['config']['rollout_ms']} ms, update {b['config']['update_ms']} ms); GEMM group {r['achieved']} TF = {r['frac']:.3f} of 416.7 (= {r['frac_of_fp32_input_mfma_peak']:.3f} of the 157.3 TF fp32-input MFMA peak); largest launch {r['largest_launch']['achieved']} TF; [128,64,32] policy {b['alt_reference_policy_dims']['value']:,.0f} env-steps/s; cpu_baseline {b['cpu_baseline']['value']:,.0f} env-steps/s on {b['cpu_baseline']['cores']} threads.  GPU boxes of the pool differ by 3-5 % (18.4-19.5 ms seen for one build) |
+| `{tag}_bench_kernel_stats.csv` | rocprofv3 `--stats` kernel table (full) |
+| `{tag}_kernel_table.md` | the table below with the per-launch HBM traffic columns |
+| `{tag}_pmc_traffic.json` | HBM bytes per minibatch GEMM group / per `lg_step` call, read by bench.py as `roofline.traffic` |
+| `{tag}_timelines.txt` | kernel-trace timeline of one minibatch and of one policy step |
+| `{tag}_gpu_tests.log` | `pytest -m gpu` on the same box ({tests.strip('= ')}) |
+| `{tag}_learning_curve.md` | learning sanity runs (ANYmal-C and A1 learn to walk in 5-6 s of wall time) |
+| `{tag}_other_configs.md` | env-steps/s of the rough-terrain and Cassie configurations |
+
+## Kernel table (3 timed + 1 warm-up iterations, + the roofline probes of bench.py)
+
+{tab}
+`k_gemm<A_RC, B_RC, EPI, TM, TN, DBUF, X6, WGM, WGN, B_PL>`: all instantiations here are the split-bf16 mainloop (X6 = true).
+EPI 0 forward (bias + activation; B_PL = weight operand from the optimiser's bf16 planes), EPI 1 input gradient (activation
+derivative + bias-gradient column sums), EPI 2 weight gradient (split-M atomics, side stream).  `2,1,...,2,4` = 128x128 tile on
+8 waves, `1,1,...,2,2` = 64x64 tile on 4 waves.  `k_substeps` is the whole control loop of one policy step (clip + 4 x (actuator
+LSTM, ABA + contact + joint limits)).
+
+Agreement with the live measurement: bench.py times one minibatch forward+backward (13 launches: gather, 4 forward GEMMs,
+loss, 7 backward GEMMs) with HIP events at {r['ms_per_minibatch']} ms; `{tag}_timelines.txt` shows the same 13 launches under the
+profiler (the two fill kernels after them belong to the probe loop, which repeats the backward pass without an optimiser
+step; the training loop has no memset per minibatch).  `largest_launch` (forward of the 512→256 layer, one net, alone):
+{r['largest_launch']['us']} µs live.
+
+## HBM traffic (PMC)
+
+`gemm_group_bytes_per_minibatch` = {tr['gemm_group_bytes_per_minibatch'] / 1e9:.2f} GB against 1.19 GB algorithmic (DESIGN.md §5 says where the
+difference is); at {r['ms_per_minibatch']} ms that is {tr['gemm_group_bytes_per_minibatch'] / r['ms_per_minibatch'] / 1e9:.2f} TB/s — the group is MFMA/issue-bound, not HBM-bound.
+`env_step_bytes_per_call` = {tr['env_step_bytes_per_call'] / 1e6:.1f} MB = {tr['env_step_bytes_per_call'] / 4096 / 1e3:.2f} KB per env-step (4.20 KB algorithmic).  Before the control loop
+was fused into one launch the same counters read 122 MB per call (scratch spills of `k_physics` 45 MB, LSTM state round
+trips 52 MB).
+
+## SQ counters of the GEMM mainloop (separate passes, tools/gemm_prof.py 4096 4096 4096 0 1; first split-bf16 build)
+
+| counter | per dispatch | reading |
+|---|---|---|
+| SQ_INSTS_MFMA | 25 165 824 | = 4096³/(32·32·16) · 6: six bf16 MFMAs per fp32 product block |
+| SQ_VALU_MFMA_BUSY_CYCLES | 805 306 368 | 32 cycles per MFMA |
+| SQ_WAVE_CYCLES / WAIT_INST_ANY / ACTIVE_INST_ANY / WAIT_ANY | 651 M / 336 M / 234 M / 81 M | 52 % issue-stall (MFMA pipe busy), 36 % issuing, 12 % parked on waitcnt/barrier |
+| SQ_LDS_BANK_CONFLICT, SQ_LDS_UNALIGNED_STALL | 0, 0 | the padded/permuted LDS image is conflict-free |
+
+MFMA pipe busy / wave time = 62 %.  `tools/gemm_clock.py` (random vs all-zero operands, same kernel): 193 vs 243 TF at 4096³ —
+the chip holds a lower clock on real data (DVFS); the fp32-input MFMA kernel runs 128 TF either way.
+"""
+open(os.path.join(pr, f"{tag}_README.md"), "w").write(txt)
+print("wrote", f"{tag}_README.md")
