@@ -2,7 +2,8 @@
 
     python tools/train_sanity.py ITERS [HIDDEN] [MODE] [ROBOT]
 
-ROBOT "anymal_c" (default, actuator net) or "a1" (Unitree A1, PD law, on a plane).
+ROBOT "anymal_c" (default, actuator net, plane), "a1" (Unitree A1, PD law, plane) or "anymal_c_rough" (mixed terrain
+with the height scan and the terrain curriculum).
 
 MODE "ref"  : the fork's anymal_c_flat config as committed (its reward is identically 0 after the
               positive clip: commands x,y are 0 so feet_air_time never pays).
@@ -30,6 +31,9 @@ from legged_gym_dev_amd.utils.helpers import class_to_dict, get_args, parse_sim_
 
 env_cfg, train_cfg = AnymalCFlatCfg(), AnymalCFlatCfgPPO()
 EnvCls = Anymal
+if robot == "anymal_c_rough":
+    from legged_gym_dev_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
+    env_cfg, train_cfg = AnymalCRoughCfg(), AnymalCRoughCfgPPO()
 if robot == "a1":
     from legged_gym_dev_amd.envs.a1.a1_config import A1RoughCfg, A1RoughCfgPPO
     from legged_gym_dev_amd.envs.base.legged_robot import LeggedRobot as EnvCls
@@ -43,8 +47,9 @@ if mode == "walk":
     r.lin_vel_x, r.lin_vel_y, r.ang_vel_yaw = [-1.0, 1.0], [-1.0, 1.0], [-1.5, 1.5]
     sc = env_cfg.rewards.scales
     for k, v in dict(tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_vel_z=-2.0, ang_vel_xy=-0.05, dof_acc=-2.5e-7,
-                     collision=-1.0, action_rate=-0.01, orientation=-5.0 if robot == "anymal_c" else -0.0,
-                     torques=-0.000025 if robot == "anymal_c" else -0.0002, feet_air_time=2.0 if robot == "anymal_c" else 1.0).items():
+                     collision=-1.0, action_rate=-0.01, orientation=-5.0 if robot == "anymal_c" else -0.0,   # ETH: -5 only in the flat ANYmal task, 0 on rough terrain / A1
+                     torques=-0.000025 if robot.startswith("anymal_c") else -0.0002,
+                     feet_air_time=2.0 if robot.startswith("anymal_c") else 1.0).items():
         setattr(sc, k, v)
 train_cfg.policy.actor_hidden_dims = list(hidden)
 train_cfg.policy.critic_hidden_dims = list(hidden)
@@ -65,9 +70,10 @@ for it in range(iters):
         ppo.t["ep_stats"].zero_()
         n = max(es[2], 1)
         bad = int((~torch.isfinite(env.root_states).all(1)).sum()) + int((~torch.isfinite(env.obs_buf).all(1)).sum())
+        lvl = float(env.terrain_levels.float().mean()) if hasattr(env, "terrain_levels") else 0.0
         trk = float(env.extras["episode"].get("rew_tracking_lin_vel", torch.zeros(()))) if "episode" in env.extras else 0.0
         print(f"it {it + 1:4d}  mean_return {es[0] / n:8.3f}  mean_ep_len {es[1] / n:7.1f}  episodes {int(es[2]):6d}  "
               f"std {float(ppo.param_views['std'].mean()):.3f} lr {ppo.learning_rate:.2e} vloss {float(vl):.4f}  "
-              f"base_z {float(env.root_states[:, 2].mean()):.3f} rew_tracking_lin_vel {trk:.4f} nonfinite_envs {bad}", flush=True)
+              f"base_z {float(env.root_states[:, 2].mean()):.3f} rew_tracking_lin_vel {trk:.4f} terrain_level {lvl:.2f} nonfinite_envs {bad}", flush=True)
 dt = time.time() - t0
 print(f"{iters} iterations in {dt:.1f}s -> {iters * 24 * 4096 / dt:.0f} env-steps/s incl. logging")
