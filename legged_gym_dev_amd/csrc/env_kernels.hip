@@ -14,55 +14,7 @@ __global__ void k_set_actions(const DevParams *__restrict__ P, const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Torque laws, one lane per (env, joint).  The actuator net (AN:71-81 + archive forward, SURVEY
-// Appendix C) keeps its 32 state floats in VGPRs; the 972 weights are wave-uniform scalar loads.
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ float lstm_row(const float *__restrict__ w, float x0, float x1, float *h0, float *c0, float *h1,
-                                          float *c1) {
-    const float *wih0 = w + 3, *whh0 = wih0 + 64, *bih0 = whh0 + 256, *bhh0 = bih0 + 32;
-    const float *wih1 = bhh0 + 32, *whh1 = wih1 + 256, *bih1 = whh1 + 256, *bhh1 = bih1 + 32;
-    const float *lw = bhh1 + 32, *lb = lw + 8;
-    const float in0 = x0 * w[0], in1 = x1 * w[1];
-    float g[32], hin[8];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        float s = bih0[r] + bhh0[r];
-        s += wih0[r * 2] * in0;
-        s += wih0[r * 2 + 1] * in1;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += whh0[r * 8 + k] * h0[k];
-        g[r] = s;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float cn = sigm(g[8 + k]) * c0[k] + sigm(g[k]) * tanhf(g[16 + k]);
-        c0[k] = cn;
-        hin[k] = sigm(g[24 + k]) * tanhf(cn);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) h0[k] = hin[k];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        float s = bih1[r] + bhh1[r];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += wih1[r * 8 + k] * hin[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += whh1[r * 8 + k] * h1[k];
-        g[r] = s;
-    }
-    float y = lb[0];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float cn = sigm(g[8 + k]) * c1[k] + sigm(g[k]) * tanhf(g[16 + k]);
-        c1[k] = cn;
-        float hn = sigm(g[24 + k]) * tanhf(cn);
-        h1[k] = hn;
-        y += lw[k] * hn;
-    }
-    return w[2] * y;
-}
-
+// PD torque laws (LR:389-413), one lane per (env, joint).  The actuator net has its own kernel below.
 __global__ void __launch_bounds__(256) k_torques(const DevParams *__restrict__ P) {
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions, n = c.num_envs * A;
@@ -73,29 +25,11 @@ __global__ void __launch_bounds__(256) k_torques(const DevParams *__restrict__ P
     const float q = st.x, qd = st.y;
     const float as = P->buf.actions[ij] * c.action_scale;
     float tau;
-    if (c.use_actuator_net) {
-        const size_t ls = (size_t)n * 8;
-        float h0[8], c0[8], h1[8], c1[8];
-        float4 *hp = reinterpret_cast<float4 *>(P->buf.lstm_h + (size_t)ij * 8);
-        float4 *cp = reinterpret_cast<float4 *>(P->buf.lstm_c + (size_t)ij * 8);
-        float4 *hp1 = reinterpret_cast<float4 *>(P->buf.lstm_h + ls + (size_t)ij * 8);
-        float4 *cp1 = reinterpret_cast<float4 *>(P->buf.lstm_c + ls + (size_t)ij * 8);
-        *reinterpret_cast<float4 *>(h0) = hp[0]; *reinterpret_cast<float4 *>(h0 + 4) = hp[1];
-        *reinterpret_cast<float4 *>(c0) = cp[0]; *reinterpret_cast<float4 *>(c0 + 4) = cp[1];
-        *reinterpret_cast<float4 *>(h1) = hp1[0]; *reinterpret_cast<float4 *>(h1 + 4) = hp1[1];
-        *reinterpret_cast<float4 *>(c1) = cp1[0]; *reinterpret_cast<float4 *>(c1 + 4) = cp1[1];
-        tau = lstm_row(c.lstm_w, as + c.default_dof_pos[j] - q, qd, h0, c0, h1, c1);
-        hp[0] = *reinterpret_cast<float4 *>(h0); hp[1] = *reinterpret_cast<float4 *>(h0 + 4);
-        cp[0] = *reinterpret_cast<float4 *>(c0); cp[1] = *reinterpret_cast<float4 *>(c0 + 4);
-        hp1[0] = *reinterpret_cast<float4 *>(h1); hp1[1] = *reinterpret_cast<float4 *>(h1 + 4);
-        cp1[0] = *reinterpret_cast<float4 *>(c1); cp1[1] = *reinterpret_cast<float4 *>(c1 + 4);
-    } else {                                                    // LR:389-413
-        if (c.control_type == 0) tau = c.p_gains[j] * (as + c.default_dof_pos[j] - q) - c.d_gains[j] * qd;
-        else if (c.control_type == 1)
-            tau = c.p_gains[j] * (as - qd) - c.d_gains[j] * (qd - P->buf.last_dof_vel[ij]) / c.sim_dt;
-        else tau = as;
-        tau = clampf(tau, -c.torque_limits[j], c.torque_limits[j]);
-    }
+    if (c.control_type == 0) tau = c.p_gains[j] * (as + c.default_dof_pos[j] - q) - c.d_gains[j] * qd;
+    else if (c.control_type == 1)
+        tau = c.p_gains[j] * (as - qd) - c.d_gains[j] * (qd - P->buf.last_dof_vel[ij]) / c.sim_dt;
+    else tau = as;
+    tau = clampf(tau, -c.torque_limits[j], c.torque_limits[j]);
     P->buf.torques[ij] = tau;
 }
 
