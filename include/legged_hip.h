@@ -158,7 +158,10 @@ int lg_set_init_done(lg_ctx *ctx, int init_done);     /* legged_robot.py:472-474
 int lg_inject_uniforms(lg_ctx *ctx, int enable);
 
 /* LeggedRobot.step (legged_robot.py:80-104): clip actions, decimation x {torque law, physics
- * substep}, post_physics_step, clip observations.  actions: device (N, A) f32. */
+ * substep}, post_physics_step, clip observations.  actions: device (N, A) f32.
+ * The clip + decimation loop is one kernel launch (state resident on chip); the result equals the
+ * sequence lg_set_actions, decimation x {lg_compute_torques, lg_simulate}, lg_post_physics_step up to
+ * fp32 rounding (masks and clipped actions bit-exactly). */
 int lg_step(lg_ctx *ctx, const float *actions);
 /* Finer-grained entry points (tests, teacher forcing): */
 int lg_set_actions(lg_ctx *ctx, const float *actions);         /* :86-87 */
@@ -209,9 +212,11 @@ int lg_ppo_process_env_step(lg_ppo *p, const float *rew, const uint8_t *dones, c
 int lg_ppo_compute_returns(lg_ppo *p, const float *last_critic_obs);
 int lg_ppo_normalize_advantages(lg_ppo *p);        /* after adv_partial was (all-)reduced */
 /* PPO.update split so the caller can all-reduce grads between the two halves: */
-int lg_ppo_begin_update(lg_ppo *p);                /* new permutation, zero loss stats */
+int lg_ppo_begin_update(lg_ppo *p);                /* new permutation, zero loss stats; re-derives the bf16 weight planes
+                                                      from params (so params may be written through lg_ppo_buffers
+                                                      between updates: checkpoint load, broadcast) */
 int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb);   /* fwd, loss, bwd -> grads (+KL tail) */
-int lg_ppo_minibatch_step(lg_ppo *p);              /* KL-adaptive lr, clip_grad_norm, Adam */
+int lg_ppo_minibatch_step(lg_ppo *p);              /* KL-adaptive lr, clip_grad_norm, Adam; clears grads */
 int lg_ppo_end_update(lg_ppo *p);                  /* finalise mean losses, clear storage */
 /* actor mean only (act_inference) for play/eval */
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows);
