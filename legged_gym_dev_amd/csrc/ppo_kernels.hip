@@ -632,6 +632,16 @@ __global__ void k_act_sample(PpoDev P, const float *__restrict__ obs, const floa
                              const float *__restrict__ mu, const float *__restrict__ val, int t, int64_t act_count, int inject) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = P.N, A = P.A, O = P.O;
+    if (t >= 0) {
+        // storage.add of the observations: rows of step t are one contiguous block, so the copy is flat and coalesced
+        // (grid-stride over the whole launch), not one strided row per lane
+        const size_t tot = (size_t)N * O, step = (size_t)gridDim.x * blockDim.x;
+        for (size_t k = i; k < tot; k += step) P.st_obs[(size_t)t * tot + k] = obs[k];
+        if (P.st_critic_obs != P.st_obs) {
+            const size_t totc = (size_t)N * P.OC;
+            for (size_t k = i; k < totc; k += step) P.st_critic_obs[(size_t)t * totc + k] = critic_obs[k];
+        }
+    }
     if (i >= N) return;
     const float *std = P.params + P.off_std;
     float lp = 0.f;
@@ -653,9 +663,6 @@ __global__ void k_act_sample(PpoDev P, const float *__restrict__ obs, const floa
     if (t >= 0) {
         P.st_values[(size_t)t * N + i] = v;
         P.st_log_prob[(size_t)t * N + i] = lp;
-        for (int k = 0; k < O; ++k) P.st_obs[((size_t)t * N + i) * O + k] = obs[(size_t)i * O + k];
-        if (P.st_critic_obs != P.st_obs)
-            for (int k = 0; k < P.OC; ++k) P.st_critic_obs[((size_t)t * N + i) * P.OC + k] = critic_obs[(size_t)i * P.OC + k];
     }
     if (i < A && t == 0) P.st_sigma[i] = std[i];
 }
@@ -1165,7 +1172,9 @@ __global__ void __launch_bounds__(256) k_opt_adam(PpoDev P, int par) {
 extern "C" {
 void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
                      int64_t cnt, int inject, hipStream_t s) {
-    hipLaunchKernelGGL(k_act_sample, dim3((P->N + 63) / 64), dim3(64), 0, s, *P, obs, cobs, mu, val, t, cnt, inject);
+    // one lane per env for the sampling; at least 256 blocks so the observation copy is spread over the chip
+    const int blocks = (P->N + 63) / 64;
+    hipLaunchKernelGGL(k_act_sample, dim3(blocks > 256 ? blocks : 256), dim3(64), 0, s, *P, obs, cobs, mu, val, t, cnt, inject);
 }
 void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, const uint8_t *tos, int t, hipStream_t s) {
     hipLaunchKernelGGL(k_process_step, dim3((P->N + 255) / 256), dim3(256), 0, s, *P, rew, dones, tos, t);
