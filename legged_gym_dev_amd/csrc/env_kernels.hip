@@ -492,6 +492,67 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
     }
 }
 
+// reset_env for ONE environment carried out by the whole workgroup (the masked in-kernel reset of k_post_step: an env
+// that resets would otherwise keep one lane busy for ~2.5 k instructions -- 20+ Philox draws, ~150 stores -- while the
+// block's other lanes wait, and the kernel lasts as long as its slowest block).  Same arithmetic, same Philox slots, so
+// the result is bit-identical to reset_env; only who computes what changes.  Call from all threads (contains barriers).
+__device__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions, N = c.num_envs, F = c.num_feet, tid = threadIdx.x;
+    float *r = P->buf.root_states + (size_t)i * 13;
+    float *org = P->buf.env_origins + (size_t)i * 3;
+    if (tid == 0 && c.curriculum && init_done) {                  // needs the pre-reset pose and commands
+        float *cmd = P->buf.commands + (size_t)i * 4;
+        float dx = r[0] - org[0], dy = r[1] - org[1];
+        float dist = sqrtf(dx * dx + dy * dy);
+        bool up = dist > c.terrain_env_length / 2.0f;
+        float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
+        bool down = (dist < cn * c.episode_length_s * 0.5f) && !up;
+        int64_t lvl = P->buf.terrain_levels[i] + (up ? 1 : 0) - (down ? 1 : 0);
+        if (lvl >= c.max_terrain_level) {
+            if (inject) lvl = P->buf.inject_levels[i];
+            else {
+                lvl = (int64_t)(uni(P, i, LG_SLOT_LEVEL, counter, 0) * c.max_terrain_level);
+                if (lvl > c.max_terrain_level - 1) lvl = c.max_terrain_level - 1;
+            }
+        } else if (lvl < 0) lvl = 0;
+        P->buf.terrain_levels[i] = lvl;
+        const float *to = P->terrain_origins + ((size_t)lvl * c.terrain_num_cols + P->buf.terrain_types[i]) * 3;
+        org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
+    }
+    __syncthreads();
+    if (tid < A) {                                                 // joint j = tid
+        const float u = uni(P, i, LG_SLOT_DOF + tid, counter, inject);
+        reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)i * A + tid] = make_float2(c.default_dof_pos[tid] * ((1.5f - 0.5f) * u + 0.5f), 0.0f);
+        P->buf.last_actions[(size_t)i * A + tid] = 0.0f;
+        P->buf.last_dof_vel[(size_t)i * A + tid] = 0.0f;
+    } else if (tid < A + 13) {                                     // root component k
+        const int k = tid - A;
+        float v = c.base_init_state[k];
+        if (k < 3) v += org[k];
+        if (k < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * uni(P, i, LG_SLOT_XY(A) + k, counter, inject) + (-1.0f);
+        if (k >= 7) v = (0.5f - (-0.5f)) * uni(P, i, LG_SLOT_VEL(A) + (k - 7), counter, inject) + (-0.5f);
+        r[k] = v;
+    } else if (tid == A + 13) {
+        resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
+        P->buf.episode_length[i] = 0;
+        P->buf.reset[i] = 1;
+    } else if (tid < A + 14 + F) {
+        P->buf.feet_air_time[(size_t)i * F + (tid - A - 14)] = 0.0f;
+    }
+    if (c.use_actuator_net) {                                      // h, c of both layers: 2 x A rows of 8 floats each
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = tid; q < 2 * A * 2; q += blockDim.x) {        // q = (layer, joint, half)
+            const int l = q / (2 * A), j = (q / 2) % A, hf = q & 1;
+            const size_t idx = ((size_t)l * N * A + (size_t)i * A + j) * 8 + 4 * hf;
+            *reinterpret_cast<float4 *>(P->buf.lstm_h + idx) = z;
+            *reinterpret_cast<float4 *>(P->buf.lstm_c + idx) = z;
+        }
+    }
+    __syncthreads();
+}
+
+
 // LR:877-915 (+ utils/math.py:38-42): one lane per (env, height point)
 __device__ __forceinline__ float height_sample(const DevParams *P, const float *r, int h) {
     const lg_cfg &c = P->cfg;
@@ -521,6 +582,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     const int tid = threadIdx.x;
     __shared__ float s_acc[LG_NUM_REWARDS];
     __shared__ int s_cnt;
+    __shared__ int s_list[TILE];                               // envs of this tile that reset this step
     if (tid < LG_NUM_REWARDS) s_acc[tid] = 0.0f;
     if (tid == 0) s_cnt = 0;
 
@@ -593,16 +655,16 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         }
         P->buf.rew[i] = rew;
         if (rst) {                                                          // LR:147-187
-            atomicAdd(&s_cnt, 1);
+            s_list[atomicAdd(&s_cnt, 1)] = i;
             for (int k = 0; k < LG_NUM_REWARDS; ++k)
                 if (c.rew_scale[k] != 0.0f) {
                     atomicAdd(&s_acc[k], P->buf.episode_sums[(size_t)k * N + i]);
                     P->buf.episode_sums[(size_t)k * N + i] = 0.0f;
                 }
-            reset_env(P, i, counter, inject, init_done);
         }
     }
     __syncthreads();
+    for (int q = 0; q < s_cnt; ++q) reset_env_coop(P, s_list[q], counter, inject, init_done);   // workgroup-uniform trip count
     if (s_cnt > 0) {
         if (tid < LG_NUM_REWARDS && c.rew_scale[tid] != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
         if (tid == 0) atomicAdd(P->reset_count, s_cnt);
