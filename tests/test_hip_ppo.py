@@ -252,3 +252,74 @@ def test_other_activations_forward_and_gradients(activation):
         assert float((got - ref).norm() / ref.norm()) < 3e-4
     finally:
         hip.close()
+
+
+def test_two_rank_update_equals_single_process_update():
+    """SURVEY.md §8(e) without a second GPU: two HipPPO shards (world_size 2, 64 envs each) whose `all_reduce` is
+    emulated by summing their buffers in-process, against one HipPPO over the 128 envs.  One minibatch per epoch, so both
+    sides average over the same samples: global advantage normalisation (3-float moment reduce), [gradient | KL] reduce,
+    /world in the optimiser kernels, KL-adaptive lr and Adam must leave all three with the same parameters
+    (rtol 2e-4 / atol 2e-6: fp32 sums in a different order)."""
+    from legged_gym_dev_amd.rl.ppo import HipPPO
+    N, O, A, T = 128, 48, 12, 8
+    policy = dict(POLICY, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32])
+    alg = dict(ALG, num_mini_batches=1, num_learning_epochs=2)
+    torch.manual_seed(5)
+    one = HipPPO(N, O, None, A, policy, alg, T, device="cuda:0", seed=5)
+    sh = [HipPPO(N // 2, O, None, A, policy, alg, T, device="cuda:0", seed=5, world_size=2, rank=r) for r in range(2)]
+    try:
+        sd = {k: v.clone() for k, v in one.state_dict().items()}
+        for s in sh:
+            s.load_state_dict(sd)
+        g = torch.Generator(device="cuda").manual_seed(8)
+        for p in [one] + sh:
+            p.inject_noise(1)
+        for t in range(T):
+            obs = torch.randn(N, O, device="cuda", generator=g)
+            noise = torch.randn(N, A, device="cuda", generator=g)
+            rew = torch.randn(N, device="cuda", generator=g)
+            dones = (torch.rand(N, device="cuda", generator=g) < 0.1).to(torch.uint8)
+            tos = ((torch.rand(N, device="cuda", generator=g) < 0.5) & (dones > 0)).to(torch.uint8)
+            for p, sl in ((one, slice(0, N)), (sh[0], slice(0, N // 2)), (sh[1], slice(N // 2, N))):
+                p.t["noise"].copy_(noise[sl])
+                p.act(obs[sl].contiguous())
+                p.process_env_step(rew[sl].contiguous(), dones[sl].contiguous(), {"time_outs": tos[sl].contiguous()})
+        last = torch.randn(N, O, device="cuda", generator=g)
+
+        def reduce_over_shards(name, n=None):
+            def f(_view):
+                tot = sh[0].t[name][:n] + sh[1].t[name][:n]
+                for s in sh:
+                    s.t[name][:n].copy_(tot)
+            return f
+        one.compute_returns(last)
+        # shards: the collective is called once per rank on its own view; emulate by summing after both have produced theirs
+        for r, s in enumerate(sh):
+            s._call("compute_returns", __import__("ctypes").c_void_p(last[r * N // 2:(r + 1) * N // 2].contiguous().data_ptr()))
+        torch.cuda.synchronize()
+        reduce_over_shards("adv_partial")(None)
+        for s in sh:
+            s._call("normalize_advantages")
+        torch.testing.assert_close(torch.cat([sh[0].t["advantages"], sh[1].t["advantages"]], dim=1), one.t["advantages"], rtol=1e-5, atol=1e-6)
+        one.update()
+        for s in sh:
+            s._call("begin_update")
+        for epoch in range(2):
+            for s in sh:
+                s._call("minibatch_backward", epoch, 0)
+            torch.cuda.synchronize()
+            reduce_over_shards("grads", sh[0].num_reduce)(None)
+            for s in sh:
+                s._call("minibatch_step")
+        for s in sh:
+            s._call("end_update")
+        torch.cuda.synchronize()
+        ref = one.t["params"][: one.num_params]
+        for s in sh:
+            torch.testing.assert_close(s.t["params"][: s.num_params], ref, rtol=2e-4, atol=2e-6)
+            assert abs(s.learning_rate - one.learning_rate) < 1e-12
+        assert torch.equal(sh[0].t["params"], sh[1].t["params"])          # ranks stay in lock-step exactly
+    finally:
+        one.close()
+        for s in sh:
+            s.close()
