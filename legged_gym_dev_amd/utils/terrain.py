@@ -79,35 +79,34 @@ class Terrain:
                                         horizontal_scale=self.cfg.horizontal_scale)
 
     def make_terrain(self, choice, difficulty):
-        t = self._blank()
-        slope = difficulty * 0.4
-        step_height = 0.05 + 0.18 * difficulty
-        obstacle_height = 0.05 + difficulty * 0.2
-        stone_size = 1.5 * (1.05 - difficulty)
-        stone_distance = 0.05 if difficulty == 0 else 0.1
-        pr = self.proportions
-        if choice < pr[0]:
-            if choice < pr[0] / 2:
-                slope *= -1
-            terrain_utils.pyramid_sloped_terrain(t, slope=slope, platform_size=3.0)
-        elif choice < pr[1]:
-            terrain_utils.pyramid_sloped_terrain(t, slope=slope, platform_size=3.0)
-            terrain_utils.random_uniform_terrain(t, min_height=-0.05, max_height=0.05, step=0.005,
-                                                 downsampled_scale=0.2)
-        elif choice < pr[3]:
-            if choice < pr[2]:
-                step_height *= -1
-            terrain_utils.pyramid_stairs_terrain(t, step_width=0.31, step_height=step_height, platform_size=3.0)
-        elif choice < pr[4]:
-            terrain_utils.discrete_obstacles_terrain(t, obstacle_height, 1.0, 2.0, 20, platform_size=3.0)
-        elif len(pr) > 5 and choice < pr[5]:
-            terrain_utils.stepping_stones_terrain(t, stone_size=stone_size, stone_distance=stone_distance,
-                                                  max_height=0.0, platform_size=4.0)
-        elif len(pr) > 6 and choice < pr[6]:
-            gap_terrain(t, gap_size=1.0 * difficulty, platform_size=3.0)
+        """One tile: `choice` in [0, 1) picks the generator through the cumulative `terrain_proportions`
+        (smooth slope up/down | rough slope | stairs down/up | discrete obstacles | stepping stones | gap | pit),
+        `difficulty` in [0, 1) scales it.  Parameter formulas and call order as in the reference (terrain.py:109-145):
+        the generators draw from numpy's global stream, so the order is part of the result."""
+        tile = self._blank()
+        edges = self.proportions
+        bucket = next((k for k, edge in enumerate(edges) if choice < edge), len(edges))
+        tu = terrain_utils
+        if bucket <= 1:
+            grade = 0.4 * difficulty
+            if bucket == 0 and choice < edges[0] / 2:
+                grade = -grade
+            tu.pyramid_sloped_terrain(tile, slope=grade, platform_size=3.0)
+            if bucket == 1:
+                tu.random_uniform_terrain(tile, min_height=-0.05, max_height=0.05, step=0.005, downsampled_scale=0.2)
+        elif bucket <= 3:
+            rise = 0.05 + 0.18 * difficulty
+            tu.pyramid_stairs_terrain(tile, step_width=0.31, step_height=-rise if bucket == 2 else rise, platform_size=3.0)
+        elif bucket == 4:
+            tu.discrete_obstacles_terrain(tile, 0.05 + 0.2 * difficulty, 1.0, 2.0, 20, platform_size=3.0)
+        elif bucket == 5 and len(edges) > 5:
+            tu.stepping_stones_terrain(tile, stone_size=1.5 * (1.05 - difficulty), stone_distance=0.05 if difficulty == 0 else 0.1,
+                                       max_height=0.0, platform_size=4.0)
+        elif bucket == 6 and len(edges) > 6:
+            gap_terrain(tile, gap_size=1.0 * difficulty, platform_size=3.0)
         else:
-            pit_terrain(t, depth=1.0 * difficulty, platform_size=4.0)
-        return t
+            pit_terrain(tile, depth=1.0 * difficulty, platform_size=4.0)
+        return tile
 
     def add_terrain_to_map(self, terrain, row, col):
         sx = self.border + row * self.length_per_env_pixels
