@@ -227,6 +227,43 @@ def cpu_baseline(num_envs, hidden):
                       f"{t_roll:.2f}s) + 1 of 20 minibatch updates ({t_mb:.2f}s, scaled x20); {cores} threads"}
 
 
+def rank_environments(n, port, base=None):
+    """Environment of each of the n child ranks (what torch.distributed.run would export)."""
+    base = dict(os.environ if base is None else base)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    return [dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)) for r in range(n)]
+
+
+def launch_ranks(n, argv):
+    """One process per GPU, started from a parent that has made no GPU call; rank 0 prints the JSON line.
+    Returns the exit code: 0 only if every rank ended cleanly; the others are stopped when one fails."""
+    import socket
+    import subprocess
+    if os.environ.get("LG_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e)
+             for e in rank_environments(n, port)]
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            r = p.poll()
+            if r is None:
+                continue
+            pending.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in pending:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,8 +278,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU yet (importing torch does not);
+        # start one fresh child per device and leave with their exit code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # rehearsal knobs (1-GPU box): LG_BENCH_BACKEND=gloo LG_BENCH_SHARE_GPU=1 run all ranks on cuda:0 over gloo
@@ -256,6 +297,8 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=torch.device(device))
         else:
             torch.distributed.init_process_group(backend)
+    if os.environ.get("LG_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: a rank that dies must fail the job
+        raise SystemExit(3)
     env, runner = make_runner(args.num_envs, hidden, device, rank, world)
     el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world

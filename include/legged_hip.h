@@ -133,7 +133,12 @@ typedef struct lg_buffers {
     float *extras_episode;                /* LG_NUM_REWARDS */
     float *extras_terrain_level;          /* 1 */
     uint8_t *extras_time_outs;            /* N */
+    float *extras_episode_acc;            /* LG_NUM_REWARDS + 2: running sums over steps of extras_episode, of extras_terrain_level
+                                             and the number of steps summed -- rsl_rl's log() averages infos["episode"] over every
+                                             step of an iteration; the reader divides and clears */
     int32_t *n_reset;                     /* 1: envs reset by the last step */
+    int32_t *n_fault;                     /* 1: envs the physics fault guard stopped during the last step (they are among n_reset) */
+    int64_t *fault_total;                 /* 1: the same, summed since lg_create */
     float *inject_uniforms;               /* (N, K) or unused */
     int64_t *inject_levels;               /* N */
 } lg_buffers;
@@ -159,9 +164,9 @@ int lg_inject_uniforms(lg_ctx *ctx, int enable);
 
 /* LeggedRobot.step (legged_robot.py:80-104): clip actions, decimation x {torque law, physics
  * substep}, post_physics_step, clip observations.  actions: device (N, A) f32.
- * The clip + decimation loop is one kernel launch (state resident on chip); the result equals the
- * sequence lg_set_actions, decimation x {lg_compute_torques, lg_simulate}, lg_post_physics_step up to
- * fp32 rounding (masks and clipped actions bit-exactly). */
+ * The clip + decimation loop is one kernel launch (state resident on chip).  lg_compute_torques and lg_simulate run
+ * the same kernel with one stage switched off, so the result equals the sequence lg_set_actions, decimation x
+ * {lg_compute_torques, lg_simulate}, lg_post_physics_step bit for bit. */
 int lg_step(lg_ctx *ctx, const float *actions);
 /* Finer-grained entry points (tests, teacher forcing): */
 int lg_set_actions(lg_ctx *ctx, const float *actions);         /* :86-87 */
@@ -169,6 +174,12 @@ int lg_compute_torques(lg_ctx *ctx);                           /* :91 (PD :389-4
 int lg_simulate(lg_ctx *ctx);                                  /* :92-96, one sim_dt of physics */
 int lg_post_physics_step(lg_ctx *ctx);                         /* :106-137 + obs clip :100-103 */
 int lg_reset_all(lg_ctx *ctx);                                 /* reset_idx(arange(N)), base_task.py:113 */
+/* reset_idx(env_ids) for an arbitrary subset (legged_robot.py:147-187): terrain curriculum, _reset_dofs + _reset_root_states
+ * (what the reference pushes through set_dof_state_tensor_indexed :428 / set_actor_root_state_tensor_indexed :452, with the
+ * same int32 id tensor), command resample, buffer clears, actuator-net state (anymal.py:56-60), extras["episode"] means
+ * over the ids and extras["time_outs"].  ids: DEVICE int32[n], local env indices, no duplicates.  n == 0 returns at once
+ * (legged_robot.py:156-157).  Draws come from the env's reset slots at the current step counter. */
+int lg_reset_ids(lg_ctx *ctx, const int32_t *ids, int n);
 
 /* ------------------------------------------------------------------ PPO (rsl_rl v1.0.2 semantics,
  * SURVEY.md Appendix B; call sites task_registry.py:148-155, scripts/train.py:44) */
@@ -193,6 +204,9 @@ typedef struct lg_ppo_buffers {
     float *adv_partial;                            /* [sum, sumsq, count] for cross-rank normalisation */
     float *cur_reward_sum, *cur_episode_len;       /* (N) running episode return / length (runner logging) */
     float *ep_stats;                               /* [sum return, sum length, count] of episodes finished since cleared */
+    float *ep_ring;                                /* (2, 100): returns / lengths of the last 100 finished episodes (rsl_rl's rewbuffer and
+                                                      lenbuffer deques); slot = finish order % 100, unordered within one step */
+    int32_t *ep_ring_count;                        /* 1: episodes finished since creation */
     int64_t num_params, num_reduce;                /* floats to all-reduce per optimiser step */
 } lg_ppo_buffers;
 

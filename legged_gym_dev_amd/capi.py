@@ -80,7 +80,8 @@ _BUF_FIELDS = [
     ("projected_gravity", PF), ("measured_heights", PF), ("env_origins", PF),
     ("terrain_levels", PI64), ("terrain_types", PI64), ("lstm_h", PF), ("lstm_c", PF),
     ("friction", PF), ("base_mass_delta", PF), ("extras_episode", PF), ("extras_terrain_level", PF),
-    ("extras_time_outs", PU8), ("n_reset", PI32), ("inject_uniforms", PF), ("inject_levels", PI64)]
+    ("extras_time_outs", PU8), ("extras_episode_acc", PF), ("n_reset", PI32), ("n_fault", PI32), ("fault_total", PI64),
+    ("inject_uniforms", PF), ("inject_levels", PI64)]
 
 
 class lg_buffers(C.Structure):
@@ -101,7 +102,9 @@ def buffer_shapes(N, A, B, O, F, H):
         "env_origins": ((N, 3), "f4"), "terrain_levels": ((N,), "i8"), "terrain_types": ((N,), "i8"),
         "lstm_h": ((2, N * A, 8), "f4"), "lstm_c": ((2, N * A, 8), "f4"), "friction": ((N,), "f4"),
         "base_mass_delta": ((N,), "f4"), "extras_episode": ((NUM_REWARDS,), "f4"),
-        "extras_terrain_level": ((1,), "f4"), "extras_time_outs": ((N,), "u1"), "n_reset": ((1,), "i4"),
+        "extras_terrain_level": ((1,), "f4"), "extras_time_outs": ((N,), "u1"),
+        "extras_episode_acc": ((NUM_REWARDS + 2,), "f4"), "n_reset": ((1,), "i4"),
+        "n_fault": ((1,), "i4"), "fault_total": ((1,), "i8"),
         "inject_uniforms": ((N, K), "f4"), "inject_levels": ((N,), "i8")}
 
 
@@ -124,7 +127,7 @@ class lg_ppo_buffers(C.Structure):
         ("advantages", PF), ("log_prob", PF), ("mu", PF), ("sigma", PF), ("dones", PU8),
         ("act_actions", PF), ("act_values", PF), ("act_log_prob", PF), ("act_mu", PF),
         ("stats", PF), ("noise", PF), ("perm", PI32), ("adv_partial", PF),
-        ("cur_reward_sum", PF), ("cur_episode_len", PF), ("ep_stats", PF),
+        ("cur_reward_sum", PF), ("cur_episode_len", PF), ("ep_stats", PF), ("ep_ring", PF), ("ep_ring_count", PI32),
         ("num_params", i64), ("num_reduce", i64)]
 
 
@@ -145,6 +148,7 @@ def declare_env_api(lib, prefix="lg_"):
     g("set_actions").argtypes = [vp, vp]
     for n in ("compute_torques", "simulate", "post_physics_step", "reset_all"):
         g(n).argtypes = [vp]
+    g("reset_ids").argtypes = [vp, vp, C.c_int]
     if prefix == "lg_":
         g("set_stream").argtypes = [vp, vp]
         lib.lg_version.restype = C.c_int
@@ -152,7 +156,7 @@ def declare_env_api(lib, prefix="lg_"):
 
 ENV_SYMBOLS = ["last_error", "create", "destroy", "get_buffers", "set_step_counter", "get_step_counter",
                "set_init_done", "inject_uniforms", "step", "set_actions", "compute_torques", "simulate",
-               "post_physics_step", "reset_all"]
+               "post_physics_step", "reset_all", "reset_ids"]
 PPO_SYMBOLS = ["ppo_create", "ppo_destroy", "ppo_get_buffers", "ppo_set_stream", "ppo_param_layout",
                "ppo_inject_noise", "ppo_act", "ppo_process_env_step", "ppo_compute_returns",
                "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_step",

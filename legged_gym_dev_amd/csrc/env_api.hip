@@ -9,11 +9,10 @@ static thread_local std::string g_err;
 void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
-extern "C" void lgk_torques(const DevParams *P, int n, int lstm, hipStream_t s);
-extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, hipStream_t s);
-extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s);
+extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s);
 extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
+extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int64_t counter, int inject, int init_done, hipStream_t s);
 
 #define HIPCHK(x)                                                                                  \
     do {                                                                                           \
@@ -30,7 +29,7 @@ static int dalloc(lg_ctx *c, T **p, size_t n, bool zero = true) {
     size_t bytes = (n ? n : 1) * sizeof(T);
     if (hipMalloc(&q, bytes) != hipSuccess) { g_err = "hipMalloc failed"; return -100; }
     if (zero && hipMemset(q, 0, bytes) != hipSuccess) { g_err = "hipMemset failed"; return -100; }
-    if (c->n_allocs >= 64) { g_err = "alloc table full"; return -101; }
+    if (c->n_allocs >= 128) { g_err = "alloc table full"; return -101; }
     c->allocs[c->n_allocs++] = q;
     *p = (T *)q;
     return 0;
@@ -144,6 +143,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     DA(b.lstm_h, (size_t)2 * N * A * 8); DA(b.lstm_c, (size_t)2 * N * A * 8);
     DA(b.friction, N); DA(b.base_mass_delta, N);
     DA(b.extras_episode, LG_NUM_REWARDS); DA(b.extras_terrain_level, 1); DA(b.extras_time_outs, N); DA(b.n_reset, 1);
+    DA(b.n_fault, 1); DA(b.fault_total, 1); DA(h.fault_count, 1); DA(b.extras_episode_acc, LG_NUM_REWARDS + 2);
     DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N);
     DA(h.ep_accum, LG_NUM_REWARDS); DA(h.reset_count, 1); DA(h.fault, N);
     {   // defaults: identity quaternion, unit friction, reset flags = 1 (base_task.py:72)
@@ -202,17 +202,16 @@ int lg_set_actions(lg_ctx *c, const float *actions) {
     lgk_set_actions(c->d, actions, c->h.cfg.num_envs * c->h.cfg.num_actions, c->stream);
     return chk_launch();
 }
-int lg_compute_torques(lg_ctx *c) {
-    lgk_torques(c->d, c->h.cfg.num_envs * c->h.cfg.num_actions, c->h.cfg.use_actuator_net, c->stream);
-    return chk_launch();
-}
-int lg_simulate(lg_ctx *c) {
-    if (lgk_physics(c->d, c->h.cfg.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg, c->stream)) {
-        g_err = "no physics kernel for this topology";
+static int run_substeps(lg_ctx *c, const float *actions, int mode, int iters) {
+    const lg_cfg &f = c->h.cfg;
+    if (lgk_substeps(c->d, actions, f.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg, f.use_actuator_net, mode, iters, c->stream)) {
+        g_err = "no control-loop kernel for this topology / actuator combination (have 4x3 PD, 4x3 actuator net, 2x6 PD)";
         return -4;
     }
     return chk_launch();
 }
+int lg_compute_torques(lg_ctx *c) { return run_substeps(c, c->h.buf.actions, 1 /*torque stage*/, 1); }
+int lg_simulate(lg_ctx *c) { return run_substeps(c, c->h.buf.actions, 2 /*physics stage*/, 1); }
 int lg_post_physics_step(lg_ctx *c) {
     c->step_counter += 1;                                       // legged_robot.py:115
     lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
@@ -222,17 +221,20 @@ int lg_reset_all(lg_ctx *c) {
     lgk_reset_all(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
     return chk_launch();
 }
+int lg_reset_ids(lg_ctx *c, const int32_t *ids, int n) {        // legged_robot.py:147-187
+    if (n < 0 || (n > 0 && !ids)) { g_err = "lg_reset_ids: bad id list"; return -1; }
+    if (n == 0) return 0;                                       // :156-157
+    lgk_reset_ids(c->d, ids, n, c->step_counter, c->inject, c->init_done, c->stream);
+    return chk_launch();
+}
 static int g_fused_substeps = 1;
 int lg_debug_set_fused(int v) { g_fused_substeps = v; return 0; }
 
 int lg_step(lg_ctx *c, const float *actions) {                  // legged_robot.py:80-104
-    int rc = -1;
+    int rc;
     if (g_fused_substeps) {                                     // one launch for clip + decimation x {torques, physics}
-        rc = lgk_substeps(c->d, actions, c->h.cfg.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg,
-                          c->h.cfg.use_actuator_net, c->stream);
-        if (!rc) rc = chk_launch();
-    }
-    if (rc == -1) {                                             // topology without a fused kernel: launch per substep
+        rc = run_substeps(c, actions, 3, c->h.cfg.decimation);
+    } else {                                                    // launch per substep (A/B and debugging)
         rc = lg_set_actions(c, actions);
         for (int d = 0; d < c->h.cfg.decimation && !rc; ++d) {
             rc = lg_compute_torques(c);

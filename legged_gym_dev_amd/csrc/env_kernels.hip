@@ -14,34 +14,14 @@ __global__ void k_set_actions(const DevParams *__restrict__ P, const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// PD torque laws (LR:389-413), one lane per (env, joint).  The actuator net has its own kernel below.
-__global__ void __launch_bounds__(256) k_torques(const DevParams *__restrict__ P) {
-    const lg_cfg &c = P->cfg;
-    const int A = c.num_actions, n = c.num_envs * A;
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ij >= n) return;
-    const int j = ij % A;
-    const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[ij];
-    const float q = st.x, qd = st.y;
-    const float as = P->buf.actions[ij] * c.action_scale;
-    float tau;
-    if (c.control_type == 0) tau = c.p_gains[j] * (as + c.default_dof_pos[j] - q) - c.d_gains[j] * qd;
-    else if (c.control_type == 1)
-        tau = c.p_gains[j] * (as - qd) - c.d_gains[j] * (qd - P->buf.last_dof_vel[ij]) / c.sim_dt;
-    else tau = as;
-    tau = clampf(tau, -c.torque_limits[j], c.torque_limits[j]);
-    P->buf.torques[ij] = tau;
-}
-
 // Actuator net, wide form: 8 lanes per (env, joint) row, lane k owns hidden unit k of both LSTM
-// layers (its 4 gate rows: 112 weights + lin_w[k] resident in VGPRs, staged through LDS once per
-// block).  The 8 hidden values of a row are exchanged with width-8 shuffles; the state (2, N*A, 8)
-// is read/written 4 B per lane, fully coalesced.  6 waves per SIMD at 4096 envs instead of <1.
+// layers (its 4 gate rows: 112 weights + lin_w[k], read from LDS).  The 8 hidden values of a row are
+// exchanged with width-8 shuffles; the state (2, N*A, 8) is read/written 4 B per lane, fully coalesced.
 __device__ __forceinline__ float fsigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // One actuator-net update of lane k (hidden unit k of both layers) of a row; w = the 972 weights in LDS.
-// Returns this lane's share of the output sum (reduced over the 8 lanes by the caller's butterflies).
+// Returns the row's output sum (reduced over the 8 lanes by butterflies).
 __device__ __forceinline__ float lstm8_update(const float *__restrict__ w, int k, float x0, float x1, float &h0, float &c0, float &h1,
                                               float &c1) {
     const float *wih0 = w + 3, *whh0 = wih0 + 64, *bih0 = whh0 + 256, *bhh0 = bih0 + 32;
@@ -77,107 +57,23 @@ __device__ __forceinline__ float lstm8_update(const float *__restrict__ w, int k
     return y;
 }
 
-__global__ void __launch_bounds__(256) k_torques_lstm8(const DevParams *__restrict__ P) {
-    const lg_cfg &c = P->cfg;
-    const int A = c.num_actions, n = c.num_envs * A;
-    __shared__ float w[LG_LSTM_NW];
-    for (int i = threadIdx.x; i < LG_LSTM_NW; i += 256) w[i] = c.lstm_w[i];
-    __syncthreads();
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    int row = gid >> 3;
-    const int k = gid & 7;
-    const bool live = row < n;
-    if (!live) row = n - 1;
-    const int j = row % A;
-    const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[row];
-    const float x0 = (P->buf.actions[row] * c.action_scale + c.default_dof_pos[j] - st.x) * w[0], x1 = st.y * w[1];
-    const size_t ls = (size_t)n * 8, idx = (size_t)row * 8 + k;
-    float h0 = P->buf.lstm_h[idx], c0 = P->buf.lstm_c[idx], h1 = P->buf.lstm_h[ls + idx], c1 = P->buf.lstm_c[ls + idx];
-    const float y = lstm8_update(w, k, x0, x1, h0, c0, h1, c1);
-    if (live) {
-        P->buf.lstm_h[idx] = h0; P->buf.lstm_c[idx] = c0; P->buf.lstm_h[ls + idx] = h1; P->buf.lstm_c[ls + idx] = c1;
-        if (k == 0) P->buf.torques[row] = w[2] * (y + w[LG_LSTM_NW - 1]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// gym.simulate replacement (LR:92-96): one wave = 64/L environments, lane = (env, leg).
-template <int L, int J>
-__global__ void __launch_bounds__(64, 1) k_physics(const DevParams *__restrict__ P) {
-    const lg_cfg &c = P->cfg;
-    const lg_model &m = P->model;
-    const int gl = blockIdx.x * 64 + threadIdx.x;
-    int env = gl / L;
-    const int leg = gl % L;
-    const bool live = env < c.num_envs;
-    if (!live) env = c.num_envs - 1;                        // keep the wave converged for the butterflies
-    const int A = L * J, B = c.num_bodies, d0 = leg * J;
-    float root[13], q[J], qd[J], tau[J];
-    const float *rp = P->buf.root_states + (size_t)env * 13;
-#pragma unroll
-    for (int k = 0; k < 13; ++k) root[k] = rp[k];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[(size_t)env * A + d0 + j];
-        q[j] = st.x; qd[j] = st.y;
-        tau[j] = P->buf.torques[(size_t)env * A + d0 + j];
-    }
-    const float fr = P->buf.friction[env], dm = P->buf.base_mass_delta[env];
-    float *cf = P->buf.contact_forces + (size_t)env * B * 3;
-    if (live)
-        for (int b = 0; b < B; ++b) {
-            const int dyn = m.body_dyn[b];
-            if ((dyn < 0 ? 0 : dyn / J) == leg) { cf[3 * b] = 0.f; cf[3 * b + 1] = 0.f; cf[3 * b + 2] = 0.f; }
-        }
-    __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
-    __shared__ float s_lk[J * LG_LK_NF * 64];
-    __shared__ float s_lt[L * LG_LT_STRIDE];                // per-leg model constants: one coalesced copy per launch
-    __shared__ float s_lm[J * 4 * 64];                      // joint-limit constraint records
-    for (int t = threadIdx.x; t < L * LG_LT_STRIDE; t += 64) s_lt[t] = (&P->leg_tab[0][0])[t];
-    __syncthreads();
-    const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
-    const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
-    for (int s = 0; s < ns; ++s) {
-        V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-        const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
-        if (fault && live && leg == 0) P->fault[env] = 1;
-        V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k)
-                if (k < P->n_leg_slots) {
-                    float *o = cf + 3 * P->slot_body[k][leg];
-                    o[0] += wgt * fslot[k].x; o[1] += wgt * fslot[k].y; o[2] += wgt * fslot[k].z;
-                }
-            if (leg == 0 && P->n_base_spheres > 0) {
-                float *o = cf + 3 * P->base_body[0];
-                o[0] += wgt * fb.x; o[1] += wgt * fb.y; o[2] += wgt * fb.z;
-            }
-        }
-    }
-    if (!live) return;
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-        reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)env * A + d0 + j] = make_float2(q[j], qd[j]);
-    if (leg == 0) {
-        float *wp = P->buf.root_states + (size_t)env * 13;
-#pragma unroll
-        for (int k = 0; k < 13; ++k) wp[k] = root[k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The control loop of LeggedRobot.step (LR:86-96) as ONE launch: clip the actions, then `decimation`
-// x {torque law, physics substep} with the robot state (root, q, qd), the actuator-net state (h, c of
-// both layers) and the model constants resident in registers / LDS for the whole loop -- read once and
-// written once per env step instead of once per substep, and 1 launch instead of 1 + 2 x decimation.
-// Block = 4 waves = 64/L environments.  Wave 0 runs the physics (lane = (env, leg), as k_physics).
-// All 256 lanes run the actuator net (8 lanes per (env, joint) row, 2J rounds per substep, the state of
-// each round in VGPRs); PD laws are evaluated by the physics lanes for their own joints.  q, qd and tau
-// cross between the two lane maps through LDS.  Results are bit-identical to the launch-per-substep
-// path (lg_set_actions / lg_compute_torques / lg_simulate), which stays as the operator-level API.
+// The control loop of LeggedRobot.step (LR:86-96): clip the actions, then `iters` x {torque law, physics substep} with
+// the robot state (root, q, qd), the actuator-net state (h, c of both layers) and the model constants resident in
+// registers / LDS for the whole loop -- read once and written once per env step instead of once per substep, and 1 launch
+// instead of 1 + 2 x decimation.  Block = 4 waves = 64/L environments.  Wave 0 runs the physics (lane = (env, leg),
+// lg_physics.h).  All 256 lanes run the actuator net (8 lanes per (env, joint) row, 2J rounds per substep, the state of
+// each round in VGPRs); PD laws are evaluated by the physics lanes for their own joints.  q, qd and tau cross between the
+// two lane maps through LDS.
+//
+// The operator-level entry points run THE SAME KERNEL with one stage switched off: lg_compute_torques = torque stage only
+// (LG_RUN_TORQUES, one iteration), lg_simulate = physics stage only with the torques read from the buffer (LG_RUN_PHYSICS).
+// One instance of the torque code and one of physics_lane serve all three, so lg_step equals the launch-per-substep
+// sequence bit for bit (fp32 loads/stores between launches are exact; tests/test_hip_env.py asserts equality).
+#define LG_RUN_TORQUES 1
+#define LG_RUN_PHYSICS 2
 template <int L, int J, bool LSTM>
-__global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in) {
+__global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
     constexpr int A = L * J, EPW = 64 / L, ROWS = EPW * A, NR = ROWS * 8 / 256;
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
@@ -185,6 +81,7 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     const int N = c.num_envs, B = c.num_bodies;
     const int env0 = blockIdx.x * EPW;
     const int nrow = min(ROWS, (N - env0) * A);              // live rows of this block
+    const bool do_tau = mode & LG_RUN_TORQUES, do_phys = mode & LG_RUN_PHYSICS;
     __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
     __shared__ float s_lt[L * LG_LT_STRIDE];
@@ -198,15 +95,16 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     for (int t = tid; t < ROWS; t += 256) {
         const bool in = t < nrow;
         const size_t r = row0 + (in ? t : 0);
-        const float a = fminf(fmaxf(a_in[r], -c.clip_actions), c.clip_actions);      // LR:86-87
+        const float a = fminf(fmaxf(a_in[r], -c.clip_actions), c.clip_actions);      // LR:86-87 (idempotent on clipped input)
         if (in) P->buf.actions[r] = a;
         const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[r];
         s_act[t] = a; s_q[t] = st.x; s_qd[t] = st.y;
+        s_tau[t] = P->buf.torques[r];
     }
     // actuator-net state of this thread's NR rows
     float h0[NR], c0[NR], h1[NR], c1[NR];
     const size_t ls = (size_t)N * A * 8;
-    if (LSTM) {
+    if (LSTM && do_tau) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int rl = r * 32 + (tid >> 3);
@@ -233,44 +131,47 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int t = live ? rl0 + j : 0;
-            q[j] = s_q[t]; qd[j] = s_qd[t];
+            q[j] = s_q[t]; qd[j] = s_qd[t]; tau[j] = s_tau[t];
         }
     }
     const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
     float *cf = P->buf.contact_forces + (size_t)env * B * 3;
-    for (int sub = 0; sub < c.decimation; ++sub) {
+    for (int sub = 0; sub < iters; ++sub) {
         // ---- torques
-        if (LSTM) {                                                          // AN:71-81
+        if (do_tau) {
+            if (LSTM) {                                                      // AN:71-81
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int rl = r * 32 + (tid >> 3), k = tid & 7;
-                const int j = rl % A;
-                const float x0 = (s_act[rl] * c.action_scale + c.default_dof_pos[j] - s_q[rl]) * s_w[0], x1 = s_qd[rl] * s_w[1];
-                const float y = lstm8_update(s_w, k, x0, x1, h0[r], c0[r], h1[r], c1[r]);
-                if (k == 0) s_tau[rl] = s_w[2] * (y + s_w[LG_LSTM_NW - 1]);
-            }
-            __syncthreads();
-            if (wave == 0) {
+                for (int r = 0; r < NR; ++r) {
+                    const int rl = r * 32 + (tid >> 3), k = tid & 7;
+                    const int j = rl % A;
+                    const float x0 = (s_act[rl] * c.action_scale + c.default_dof_pos[j] - s_q[rl]) * s_w[0], x1 = s_qd[rl] * s_w[1];
+                    const float y = lstm8_update(s_w, k, x0, x1, h0[r], c0[r], h1[r], c1[r]);
+                    if (k == 0) s_tau[rl] = s_w[2] * (y + s_w[LG_LSTM_NW - 1]);
+                }
+                __syncthreads();
+                if (wave == 0) {
 #pragma unroll
-                for (int j = 0; j < J; ++j) tau[j] = s_tau[live ? rl0 + j : 0];
-            }
-        } else if (wave == 0) {                                              // LR:389-413
+                    for (int j = 0; j < J; ++j) tau[j] = s_tau[live ? rl0 + j : 0];
+                }
+            } else if (wave == 0) {                                          // LR:389-413
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const int d = leg * J + j;
-                const float as = s_act[live ? rl0 + j : 0] * c.action_scale;
-                float t;
-                if (c.control_type == 0) t = c.p_gains[d] * (as + c.default_dof_pos[d] - q[j]) - c.d_gains[d] * qd[j];
-                else if (c.control_type == 1)
-                    t = c.p_gains[d] * (as - qd[j]) - c.d_gains[d] * (qd[j] - P->buf.last_dof_vel[(size_t)env * A + d]) / c.sim_dt;
-                else t = as;
-                tau[j] = clampf(t, -c.torque_limits[d], c.torque_limits[d]);
+                for (int j = 0; j < J; ++j) {
+                    const int d = leg * J + j;
+                    const float as = s_act[live ? rl0 + j : 0] * c.action_scale;
+                    float t;
+                    if (c.control_type == 0) t = c.p_gains[d] * (as + c.default_dof_pos[d] - q[j]) - c.d_gains[d] * qd[j];
+                    else if (c.control_type == 1)
+                        t = c.p_gains[d] * (as - qd[j]) - c.d_gains[d] * (qd[j] - P->buf.last_dof_vel[(size_t)env * A + d]) / c.sim_dt;
+                    else t = as;
+                    tau[j] = clampf(t, -c.torque_limits[d], c.torque_limits[d]);
+                    if (live) s_tau[rl0 + j] = tau[j];
+                }
             }
         }
         // ---- physics
-        if (wave == 0) {
-            const bool last = sub == c.decimation - 1;
+        if (do_phys && wave == 0) {
+            const bool last = sub == iters - 1;
             if (last && live)
                 for (int b = 0; b < B; ++b) {
                     const int dyn = m.body_dyn[b];
@@ -296,17 +197,17 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
             }
             if (live) {
 #pragma unroll
-                for (int j = 0; j < J; ++j) { s_q[rl0 + j] = q[j]; s_qd[rl0 + j] = qd[j]; if (!LSTM) s_tau[rl0 + j] = tau[j]; }
+                for (int j = 0; j < J; ++j) { s_q[rl0 + j] = q[j]; s_qd[rl0 + j] = qd[j]; }
             }
         }
         __syncthreads();
     }
-    // ---- write back (once per env step)
+    // ---- write back (once per launch)
     for (int t = tid; t < nrow; t += 256) {
-        reinterpret_cast<float2 *>(P->buf.dof_state)[row0 + t] = make_float2(s_q[t], s_qd[t]);
-        P->buf.torques[row0 + t] = s_tau[t];
+        if (do_phys) reinterpret_cast<float2 *>(P->buf.dof_state)[row0 + t] = make_float2(s_q[t], s_qd[t]);
+        if (do_tau) P->buf.torques[row0 + t] = s_tau[t];
     }
-    if (LSTM) {
+    if (LSTM && do_tau) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int rl = r * 32 + (tid >> 3);
@@ -316,7 +217,7 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
             }
         }
     }
-    if (wave == 0 && live && leg == 0) {
+    if (do_phys && wave == 0 && live && leg == 0) {
         float *wp = P->buf.root_states + (size_t)env * 13;
 #pragma unroll
         for (int k = 0; k < 13; ++k) wp[k] = root[k];
@@ -581,10 +482,10 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     const int nE = min(TILE, N - env0);
     const int tid = threadIdx.x;
     __shared__ float s_acc[LG_NUM_REWARDS];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt, s_flt;
     __shared__ int s_list[TILE];                               // envs of this tile that reset this step
     if (tid < LG_NUM_REWARDS) s_acc[tid] = 0.0f;
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) { s_cnt = 0; s_flt = 0; }
 
     // ---- phase H: height scan of the pre-reset pose (LR:356-357)
     if (c.measure_heights) {
@@ -631,7 +532,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         }
         bool rst = false;                                                   // LR:139-145
         for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
-        if (P->fault[i]) { rst = true; P->fault[i] = 0; }               // physics fault guard (lg_physics.h)
+        if (P->fault[i]) { rst = true; P->fault[i] = 0; atomicAdd(&s_flt, 1); }   // physics fault guard (lg_physics.h)
         const bool to = ep > c.max_episode_length;
         rst = rst || to;
         P->buf.time_out[i] = to;
@@ -668,6 +569,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     if (s_cnt > 0) {
         if (tid < LG_NUM_REWARDS && c.rew_scale[tid] != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
         if (tid == 0) atomicAdd(P->reset_count, s_cnt);
+        if (tid == 0 && s_flt > 0) atomicAdd(P->fault_count, s_flt);
     }
 
     // ---- phase O: observations (LR:208-226), clip (LR:100-103), bookkeeping (LR:132-134)
@@ -722,8 +624,34 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
         }
     }
     __syncthreads();
-    if (tid == 0) { P->buf.n_reset[0] = n; *P->reset_count = 0; }
+    __syncthreads();
+    if (tid < LG_NUM_REWARDS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
+    if (tid == 0) {
+        P->buf.extras_episode_acc[LG_NUM_REWARDS] += P->buf.extras_terrain_level[0];
+        P->buf.extras_episode_acc[LG_NUM_REWARDS + 1] += 1.0f;
+        P->buf.n_reset[0] = n; *P->reset_count = 0;
+        const int nf = *P->fault_count;
+        P->buf.n_fault[0] = nf; P->buf.fault_total[0] += nf; *P->fault_count = 0;
+    }
     if (tid < LG_NUM_REWARDS) P->ep_accum[tid] = 0.0f;
+}
+
+// reset_idx(env_ids) for a caller-given subset (LR:147-187): one workgroup per id.  The episode-sum means of the
+// subset go through the same accumulators as the in-step resets and k_finalize publishes them.
+__global__ void __launch_bounds__(LG_TILE_THREADS) k_reset_ids(const DevParams *__restrict__ P, const int32_t *__restrict__ ids, int n,
+                                                                int64_t counter, int inject, int init_done) {
+    const lg_cfg &c = P->cfg;
+    const int N = c.num_envs, tid = threadIdx.x;
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {         // workgroup-uniform
+        const int i = ids[q];
+        if (i < 0 || i >= N) continue;
+        if (tid < LG_NUM_REWARDS && c.rew_scale[tid] != 0.0f) {
+            atomicAdd(P->ep_accum + tid, P->buf.episode_sums[(size_t)tid * N + i]);
+            P->buf.episode_sums[(size_t)tid * N + i] = 0.0f;
+        }
+        if (tid == 0) atomicAdd(P->reset_count, 1);
+        reset_env_coop(P, i, counter, inject, init_done);
+    }
 }
 
 // reset_idx(arange(N)) (base_task.py:113): no logging
@@ -739,22 +667,11 @@ extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipSt
     int blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_set_actions, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, P, a);
 }
-extern "C" void lgk_torques(const DevParams *P, int n, int lstm, hipStream_t s) {
-    if (lstm) hipLaunchKernelGGL(k_torques_lstm8, dim3((n * 8 + 255) / 256), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL(k_torques, dim3((n + 255) / 256), dim3(256), 0, s, P);
-}
-extern "C" int lgk_physics(const DevParams *P, int N, int L, int J, hipStream_t s) {
-    const int blocks = (N * L + 63) / 64;
-    if (L == 4 && J == 3) hipLaunchKernelGGL((k_physics<4, 3>), dim3(blocks), dim3(64), 0, s, P);
-    else if (L == 2 && J == 6) hipLaunchKernelGGL((k_physics<2, 6>), dim3(blocks), dim3(64), 0, s, P);
-    else return -1;
-    return 0;
-}
-extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, hipStream_t s) {
+extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s) {
     const int blocks = (N + 64 / L - 1) / (64 / L);
-    if (L == 4 && J == 3 && lstm) hipLaunchKernelGGL((k_substeps<4, 3, true>), dim3(blocks), dim3(256), 0, s, P, a_in);
-    else if (L == 4 && J == 3) hipLaunchKernelGGL((k_substeps<4, 3, false>), dim3(blocks), dim3(256), 0, s, P, a_in);
-    else if (L == 2 && J == 6 && !lstm) hipLaunchKernelGGL((k_substeps<2, 6, false>), dim3(blocks), dim3(256), 0, s, P, a_in);
+    if (L == 4 && J == 3 && lstm) hipLaunchKernelGGL((k_substeps<4, 3, true>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+    else if (L == 4 && J == 3) hipLaunchKernelGGL((k_substeps<4, 3, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+    else if (L == 2 && J == 6 && !lstm) hipLaunchKernelGGL((k_substeps<2, 6, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
     else return -1;
     return 0;
 }
@@ -765,4 +682,8 @@ extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int in
 }
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);
+}
+extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int64_t counter, int inject, int init_done, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_ids, dim3(n < 1024 ? n : 1024), dim3(LG_TILE_THREADS), 0, s, P, ids, n, counter, inject, init_done);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P);
 }

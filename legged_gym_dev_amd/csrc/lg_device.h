@@ -31,6 +31,7 @@ struct DevParams {
     const int16_t *height_samples; // hf_rows x hf_cols
     float *ep_accum;               // LG_NUM_REWARDS sums of episode_sums over resetting envs
     int32_t *reset_count;          // 1
+    int32_t *fault_count;          // 1: faults consumed by the running step (block atomics), folded by k_finalize
     uint8_t *fault;                // N: set by the physics fault guard, consumed by the post-step
     int K;                         // uniforms per env
     // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
@@ -53,7 +54,7 @@ struct lg_ctx {
     hipStream_t stream;
     int64_t step_counter;
     int init_done, inject;
-    void *allocs[64];
+    void *allocs[128];
     int n_allocs;
 };
 

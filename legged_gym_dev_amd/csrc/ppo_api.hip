@@ -21,6 +21,7 @@ void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, 
 void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s);
 void ppok_adv_normalize(const PpoDev *P, hipStream_t s);
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s);
+void ppok_randperm(const PpoDev *P, int n, uint64_t update_idx, hipStream_t s);
 void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s);
 void ppok_step(const PpoDev *P, int par, hipStream_t s);
 int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
@@ -51,8 +52,7 @@ struct lg_ppo {
     int64_t act_count, update_count;
     int Mmax;
     std::vector<void *> allocs;
-    std::vector<int32_t> perm_host;
-    uint64_t perm_state;
+    int64_t perm_count;                      // updates begun: keys the device-side minibatch permutation
     lg_ppo_buffers pub;
 };
 
@@ -189,7 +189,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         lg_set_error("stream/event creation failed"); delete p; return -100;
     }
     p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0;
-    p->perm_state = cfg->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    p->perm_count = 0;
     const int R = (int)((long)N * T / cfg->num_mini_batches);
     p->Mmax = R > N ? R : N;
 
@@ -254,7 +254,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     PA(d.mb_obs, (size_t)R * O);
     if (cfg->num_critic_obs > 0) PA(d.mb_critic_obs, (size_t)R * OC); else d.mb_critic_obs = d.mb_obs;
     PA(d.mb_actions, (size_t)R * A); PA(d.mb_mu, (size_t)R * A); PA(d.mb_scalars, (size_t)R * 4);
-    PA(d.cur_reward_sum, N); PA(d.cur_episode_len, N); PA(d.ep_stats, 4);
+    PA(d.cur_reward_sum, N); PA(d.cur_episode_len, N); PA(d.ep_stats, 4); PA(d.ep_ring, 200); PA(d.ep_ring_count, 1);
     for (int z = 0; z < 2; ++z) {
         Net &n = p->net[z];
         n.act[0] = nullptr; n.dz[0] = nullptr;
@@ -266,7 +266,6 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         float lr = cfg->learning_rate;
         (void)hipMemcpy(d.stats, &lr, sizeof(float), hipMemcpyHostToDevice);
     }
-    p->perm_host.resize(TN);
     lg_ppo_buffers &b = p->pub;
     memset(&b, 0, sizeof(b));
     b.params = d.params; b.grads = d.grads; b.adam_m = d.adam_m; b.adam_v = d.adam_v;
@@ -276,6 +275,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     b.act_actions = d.act_actions; b.act_values = d.act_values; b.act_log_prob = d.act_log_prob; b.act_mu = d.act_mu;
     b.stats = d.stats; b.noise = d.noise; b.perm = d.perm; b.adv_partial = d.adv_partial;
     b.cur_reward_sum = d.cur_reward_sum; b.cur_episode_len = d.cur_episode_len; b.ep_stats = d.ep_stats;
+    b.ep_ring = d.ep_ring; b.ep_ring_count = d.ep_ring_count;
     b.num_params = off; b.num_reduce = off + 2;
     if (hipDeviceSynchronize() != hipSuccess) { lg_set_error("device sync failed in lg_ppo_create"); lg_ppo_destroy(p); return -100; }
     *out = p;
@@ -352,19 +352,9 @@ int lg_ppo_normalize_advantages(lg_ppo *p) {
 }
 
 int lg_ppo_begin_update(lg_ppo *p) {
-    // randperm(num_mini_batches * mini_batch_size), drawn once per update (Appendix B)
+    // randperm(num_mini_batches * mini_batch_size), drawn once per update and reused by every epoch (Appendix B): on the device
     const size_t n = (size_t)p->dev.mb_rows * p->cfg.num_mini_batches;
-    for (size_t i = 0; i < n; ++i) p->perm_host[i] = (int32_t)i;
-    uint64_t s = p->perm_state;
-    for (size_t i = n - 1; i > 0; --i) {
-        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-        size_t j = (size_t)(s % (i + 1));
-        int32_t t = p->perm_host[i]; p->perm_host[i] = p->perm_host[j]; p->perm_host[j] = t;
-    }
-    p->perm_state = s;
-    if (hipMemcpyAsync(p->dev.perm, p->perm_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, p->stream) != hipSuccess) {
-        lg_set_error("perm upload failed"); return -100;
-    }
+    ppok_randperm(&p->dev, (int)n, (uint64_t)p->perm_count++, p->stream);
     (void)hipMemsetAsync(p->dev.stats + 2, 0, 2 * sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.stats + 5, 0, sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.loss_acc, 0, 4 * sizeof(float), p->stream);

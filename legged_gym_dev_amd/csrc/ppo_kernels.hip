@@ -642,8 +642,11 @@ __global__ void k_act_sample(PpoDev P, const float *__restrict__ obs, const floa
             for (size_t k = i; k < totc; k += step) P.st_critic_obs[(size_t)t * totc + k] = critic_obs[k];
         }
     }
-    if (i >= N) return;
     const float *std = P.params + P.off_std;
+    // sigma the rollout was sampled with (PPO.update's old_sigma_batch); before the row guard: with fewer envs than
+    // action dimensions the lanes i in [N, A) would otherwise leave it at zero and the KL term at inf
+    if (i < A && t == 0) P.st_sigma[i] = std[i];
+    if (i >= N) return;
     float lp = 0.f;
     for (int a = 0; a < A; ++a) {
         float m = mu[(size_t)i * A + a], s = std[a];
@@ -664,7 +667,6 @@ __global__ void k_act_sample(PpoDev P, const float *__restrict__ obs, const floa
         P.st_values[(size_t)t * N + i] = v;
         P.st_log_prob[(size_t)t * N + i] = lp;
     }
-    if (i < A && t == 0) P.st_sigma[i] = std[i];
 }
 
 // PPO.process_env_step: rewards += gamma * V * time_outs ; store
@@ -682,6 +684,9 @@ __global__ void k_process_step(PpoDev P, const float *__restrict__ rew, const ui
         atomicAdd(&P.ep_stats[0], cr);
         atomicAdd(&P.ep_stats[1], cl);
         atomicAdd(&P.ep_stats[2], 1.0f);
+        const int slot = (int)((unsigned)atomicAdd(P.ep_ring_count, 1) % 100u);   // rewbuffer / lenbuffer = deque(maxlen=100)
+        P.ep_ring[slot] = cr;
+        P.ep_ring[100 + slot] = cl;
         P.cur_reward_sum[i] = 0.f;
         P.cur_episode_len[i] = 0.f;
     } else {
@@ -733,6 +738,30 @@ __global__ void k_adv_normalize(PpoDev P) {
     for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
         P.st_adv[k] = (P.st_adv[k] - mean) * inv;
     if (blockIdx.x == 0 && threadIdx.x == 0) { P.stats[6] = mean; P.stats[7] = sqrtf(var); }
+}
+
+// mini_batch_generator's randperm(T*N), drawn on the device once per update and reused by every epoch:
+// a keyed bijection of [0, 2^b) -- b = bits of n rounded up to even, 6-round balanced Feistel whose round function is one
+// Philox block keyed by (seed, update index, round) -- restricted to [0, n) by cycle walking (re-encrypt until the value
+// falls below n: a bijection of the superset walks every element of [0, n) to a distinct element of [0, n)).  No sort, no
+// host round trip; each lane is independent.  Not torch.randperm's stream (parity with rsl_rl's sample order is unpinned).
+__global__ void __launch_bounds__(256) k_randperm(PpoDev P, int n, int half_bits, uint64_t update_idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t x = (uint32_t)i;
+    do {
+        uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll 1
+        for (int round = 0; round < 6; ++round) {
+            uint32_t c[4] = {r, (uint32_t)round, (uint32_t)update_idx, (uint32_t)(update_idx >> 32) ^ 0x9e3779b9u};
+            philox4x32((uint32_t)P.seed, (uint32_t)(P.seed >> 32), c);
+            const uint32_t t = l ^ (c[0] & mask);
+            l = r; r = t;
+        }
+        x = (l << half_bits) | r;
+    } while (x >= (uint32_t)n);
+    P.perm[i] = (int32_t)x;
 }
 
 // mini_batch_generator: rows perm[mb*R .. (mb+1)*R) of the (T*N)-flattened storage
@@ -1185,6 +1214,12 @@ void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s) {
 }
 void ppok_adv_normalize(const PpoDev *P, hipStream_t s) {
     hipLaunchKernelGGL(k_adv_normalize, dim3(256), dim3(256), 0, s, *P);
+}
+void ppok_randperm(const PpoDev *P, int n, uint64_t update_idx, hipStream_t s) {
+    int bits = 2;
+    while ((1ll << bits) < n) ++bits;
+    bits += bits & 1;                                          // balanced halves
+    hipLaunchKernelGGL(k_randperm, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, bits / 2, update_idx);
 }
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
     if ((P->O & 3) == 0 && (P->A & 3) == 0 && (P->OC & 3) == 0)

@@ -79,6 +79,19 @@ class EnvSetup:
         if use_curr:
             raise NotImplementedError("command/push curriculum (cfg.curriculum.use_curriculum) is not supported")
 
+        # randomisations the reference applies in its property callbacks (legged_robot.py:284-299,337-339) that have no
+        # counterpart in this physics: refuse them rather than ignore them silently
+        dr = cfg.domain_rand
+        rsp = getattr(dr, "rigid_shape_properties", None)
+        unsupported = [n for n in ("randomize_inv_base_mass",) if getattr(dr, n, False)]
+        unsupported += [n for n in ("randomize_restitution", "randomize_compliance", "randomize_thickness")
+                        if rsp is not None and getattr(rsp, n, False)]
+        dofp = getattr(dr, "dof_properties", None)
+        unsupported += [n for n in ("randomize_stiffness", "randomize_damping", "randomize_friction", "randomize_armature")
+                        if dofp is not None and getattr(dofp, n, False)]
+        if unsupported:
+            raise NotImplementedError(f"domain_rand flags without an implementation in the HIP physics: {unsupported}")
+
         # ---- body index sets (substring match on names)
         feet = [i for i, s in enumerate(self.body_names) if cfg.asset.foot_name in s]
         pen = []

@@ -96,6 +96,7 @@ class LeggedRobot(BaseTask):
         t["env_origins"].copy_(consts["env_origins"][lo:hi])
         t["friction"].copy_(consts["friction"][lo:hi])
         t["base_mass_delta"].copy_(consts["base_mass_delta"][lo:hi])
+        self.fault_total, self.n_fault = t["fault_total"], t["n_fault"]
         if "terrain_levels" in consts:
             t["terrain_levels"].copy_(consts["terrain_levels"][lo:hi])
             t["terrain_types"].copy_(consts["terrain_types"][lo:hi])
@@ -163,14 +164,20 @@ class LeggedRobot(BaseTask):
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def reset_idx(self, env_ids):
-        n = len(env_ids)
+        """legged_robot.py:147-187 for any subset of envs: one lg_reset_ids call (ids stay on the device)."""
+        ids = torch.as_tensor(env_ids, device=self.device).reshape(-1)
+        n = int(ids.numel())
         if n == 0:
             return
-        if n != self.num_envs:
-            raise NotImplementedError("reset_idx of an arbitrary subset from Python is not part of the hot path; "
-                                      "resets happen inside lg_step.  Only reset_idx(all envs) is supported.")
         self.core.lib.lg_set_init_done(self.core.ctx, int(self.init_done))
-        self.core.call("reset_all")
+        if n == self.num_envs:
+            self.core.call("reset_all")               # reset_idx(arange(N)) of BaseTask.reset(): no episode logging needed
+            return
+        self._reset_ids = ids.to(torch.int32).contiguous()    # kept alive until the next call (the launch is asynchronous)
+        self.core.call("reset_ids", C.c_void_p(self._reset_ids.data_ptr()), n)
+        self.extras["episode"] = self._extras_episode
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self._extras_time_outs
 
     def post_physics_step(self):
         self.core.call("post_physics_step")

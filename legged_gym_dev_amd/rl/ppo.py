@@ -73,13 +73,14 @@ class HipPPO:
                   "values": (T, N), "returns": (T, N), "advantages": (T, N), "log_prob": (T, N), "mu": (T, N, A),
                   "sigma": (A,), "act_actions": (N, A), "act_values": (N,), "act_log_prob": (N,), "act_mu": (N, A),
                   "stats": (8,), "noise": (N, A), "adv_partial": (4,), "cur_reward_sum": (N,), "cur_episode_len": (N,),
-                  "ep_stats": (4,)}
+                  "ep_stats": (4,), "ep_ring": (2, 100)}
         self.t = {}
         for name, shape in shapes.items():
             ptr = C.cast(getattr(b, name), C.c_void_p).value
             self.t[name] = device_tensor(ptr, shape, "f4", self, self.device)
         self.t["dones"] = device_tensor(C.cast(b.dones, C.c_void_p).value, (T, N), "u1", self, self.device)
         self.t["perm"] = device_tensor(C.cast(b.perm, C.c_void_p).value, (T * N,), "i4", self, self.device)
+        self.t["ep_ring_count"] = device_tensor(C.cast(b.ep_ring_count, C.c_void_p).value, (1,), "i4", self, self.device)
         # named parameter views, ActorCritic.parameters() order
         offs = (C.c_int64 * 32)()
         shp = (C.c_int64 * 64)()

@@ -8,11 +8,13 @@ The rollout loop issues only asynchronous C-ABI calls; the host synchronises onc
 (for the timers that define the env-steps/s metric).
 """
 import os
+import statistics
 import time
 from collections import deque
 
 import torch
 
+from legged_gym_dev_amd.capi import REWARD_NAMES as _REWARD_NAMES
 from .ppo import HipPPO
 
 
@@ -66,15 +68,36 @@ class _Alg:
         return self.ppo.learning_rate
 
 
+class TorchDistComm:
+    """The collective of the multi-GPU path as the runner sees it: rank, world_size, all_reduce(SUM), broadcast.
+    Default implementation over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for rehearsals)."""
+
+    def __init__(self):
+        self.rank, self.world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
+
+    def all_reduce(self, t):
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+
+    def broadcast(self, t, src=0):
+        torch.distributed.broadcast(t, src=src)
+
+
 class OnPolicyRunner:
-    def __init__(self, env, train_cfg, log_dir=None, device="cuda:0", wandb_callback=None):
+    def __init__(self, env, train_cfg, log_dir=None, device="cuda:0", wandb_callback=None, comm=None):
         self.cfg = train_cfg["runner"]
         self.alg_cfg, self.policy_cfg = train_cfg["algorithm"], train_cfg["policy"]
         self.device = str(device).replace("hip", "cuda")
         self.env = env
         self.wandb_callback = wandb_callback
-        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if torch.distributed.is_initialized() else 1
-        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        if comm is None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            comm = TorchDistComm()
+        self.comm = comm if comm is not None and comm.world_size > 1 else None
+        self.world_size = self.comm.world_size if self.comm else 1
+        self.rank = self.comm.rank if self.comm else 0
+        if getattr(env, "world_size", 1) != self.world_size or getattr(env, "rank", 0) != self.rank:
+            raise RuntimeError(f"env was built for rank {getattr(env, 'rank', 0)} of {getattr(env, 'world_size', 1)} but the process "
+                               f"group says rank {self.rank} of {self.world_size}: pass rank/world_size to make_env so that every "
+                               "rank owns its own env shard (env_offset, constants, Philox streams)")
         if str(torch.device(self.device)) != str(torch.device(env.device)):
             raise RuntimeError(f"rl_device {self.device} != sim_device {env.device}: the HIP learner consumes the env's "
                                "HBM buffers in place")
@@ -85,8 +108,9 @@ class OnPolicyRunner:
                           self.num_steps_per_env, device=self.device, seed=train_cfg.get("seed", 1),
                           world_size=self.world_size, rank=self.rank)
         self.alg = _Alg(self.ppo)
-        if self.world_size > 1:                       # identical initial policy on every rank
-            torch.distributed.broadcast(self.ppo.t["params"], src=0)
+        if self.comm:                                 # identical initial policy on every rank
+            torch.cuda.synchronize()
+            self.comm.broadcast(self.ppo.t["params"], src=0)
         self.log_dir = log_dir
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.rewbuffer, self.lenbuffer = deque(maxlen=100), deque(maxlen=100)
@@ -94,7 +118,7 @@ class OnPolicyRunner:
         _, _ = self.env.reset()
 
     def _all_reduce(self, t):
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        self.comm.all_reduce(t)
 
     # ------------------------------------------------------------------
     def rollout(self):
@@ -137,13 +161,23 @@ class OnPolicyRunner:
         self.tot_time += collection_time + learn_time
         fps = int(steps / (collection_time + learn_time))
         self.last_fps = fps
-        es = ppo.t["ep_stats"].cpu().tolist()
+        # rsl_rl bookkeeping, kept on the device by k_process_step / k_finalize and fetched once per iteration:
+        # rewbuffer / lenbuffer = the last 100 finished episodes; ep_infos = infos["episode"] of every step, averaged
+        ring, cnt = ppo.t["ep_ring"].cpu(), int(ppo.t["ep_ring_count"].cpu())
+        k = min(cnt, 100)
+        self.rewbuffer, self.lenbuffer = deque(ring[0, :k].tolist(), maxlen=100), deque(ring[1, :k].tolist(), maxlen=100)
         ppo.t["ep_stats"].zero_()
-        if es[2] > 0:
-            self.rewbuffer.append(es[0] / es[2])
-            self.lenbuffer.append(es[1] / es[2])
         mean_std = float(ppo.param_views["std"].mean())
-        ep = {k: float(v) for k, v in self.env.extras.get("episode", {}).items()}
+        acc = self.env.core.t["extras_episode_acc"].cpu()
+        self.env.core.t["extras_episode_acc"].zero_()
+        nsteps = max(float(acc[-1]), 1.0)
+        ep = {}
+        for name in self.env.extras.get("episode", {}):
+            if name == "terrain_level":
+                ep[name] = float(acc[-2]) / nsteps
+            elif name.startswith("rew_") and name[4:] in _REWARD_NAMES:
+                ep[name] = float(acc[_REWARD_NAMES.index(name[4:])]) / nsteps
+        faults = int(self.env.core.t["fault_total"].cpu())
         if self.rank != 0:
             return
         lines = [f" Learning iteration {it}/{tot_iter} ".center(width, " "), "",
@@ -151,8 +185,11 @@ class OnPolicyRunner:
                  f"{'Value function loss:':>{pad}} {vloss:.4f}", f"{'Surrogate loss:':>{pad}} {sloss:.4f}",
                  f"{'Mean action noise std:':>{pad}} {mean_std:.2f}", f"{'Learning rate:':>{pad}} {ppo.learning_rate:.2e}"]
         if self.rewbuffer:
-            lines += [f"{'Mean reward:':>{pad}} {self.rewbuffer[-1]:.2f}", f"{'Mean episode length:':>{pad}} {self.lenbuffer[-1]:.2f}"]
+            lines += [f"{'Mean reward:':>{pad}} {statistics.mean(self.rewbuffer):.2f}",
+                      f"{'Mean episode length:':>{pad}} {statistics.mean(self.lenbuffer):.2f}"]
         lines += [f"{'Mean episode ' + k + ':':>{pad}} {v:.4f}" for k, v in ep.items()]
+        if faults:
+            lines += [f"{'Physics fault resets (total):':>{pad}} {faults}"]
         lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}",
                   f"{'Iteration time:':>{pad}} {collection_time + learn_time:.2f}s", f"{'Total time:':>{pad}} {self.tot_time:.2f}s"]
         print("#" * width + "\n" + "\n".join(lines) + "\n", flush=True)

@@ -39,11 +39,12 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
     z(e->base_ang_vel, (size_t)N * 3); z(e->proj_grav, (size_t)N * 3); z(e->heights, (size_t)N * (H ? H : 1));
     z(e->env_origins, (size_t)N * 3); z(e->lstm_h, (size_t)2 * N * A * 8); z(e->lstm_c, (size_t)2 * N * A * 8);
     z(e->friction, N); z(e->base_mass_delta, N); z(e->extras_episode, LG_NUM_REWARDS);
-    z(e->extras_terrain_level, 1); z(e->inj_u, (size_t)N * e->K);
+    z(e->extras_terrain_level, 1); z(e->extras_episode_acc, LG_NUM_REWARDS + 2); z(e->inj_u, (size_t)N * e->K);
     for (int i = 0; i < N; ++i) { e->root[(size_t)i * 13 + 6] = 1.0f; e->friction[i] = 1.0f; }
     e->reset.assign(N, 1); e->time_out.assign(N, 0); e->last_contacts.assign((size_t)N * F, 0);
     e->extras_time_outs.assign(N, 0); e->fault.assign(N, 0); e->ep_len.assign(N, 0); e->terrain_levels.assign(N, 0);
     e->terrain_types.assign(N, 0); e->inj_levels.assign(N, 0); e->n_reset.assign(1, 0);
+    e->n_fault.assign(1, 0); e->fault_total.assign(1, 0);
     *out = e;
     return 0;
 }
@@ -65,6 +66,7 @@ int lgo_get_buffers(void *ctx, lg_buffers *b) {
     b->friction = e->friction.data(); b->base_mass_delta = e->base_mass_delta.data();
     b->extras_episode = e->extras_episode.data(); b->extras_terrain_level = e->extras_terrain_level.data();
     b->extras_time_outs = e->extras_time_outs.data(); b->n_reset = e->n_reset.data();
+    b->extras_episode_acc = e->extras_episode_acc.data(); b->n_fault = e->n_fault.data(); b->fault_total = e->fault_total.data();
     b->inject_uniforms = e->inj_u.data(); b->inject_levels = e->inj_levels.data();
     return 0;
 }
@@ -84,6 +86,7 @@ int lgo_compute_torques(void *ctx) { compute_torques(*(Env *)ctx); return 0; }
 int lgo_simulate(void *ctx) { simulate(*(Env *)ctx); return 0; }
 int lgo_post_physics_step(void *ctx) { post_physics_step(*(Env *)ctx); return 0; }
 int lgo_reset_all(void *ctx) { reset_all(*(Env *)ctx); return 0; }
+int lgo_reset_ids(void *ctx, const int32_t *ids, int n) { reset_ids(*(Env *)ctx, ids, n); return 0; }
 
 int lgo_step(void *ctx, const float *actions) {                        // legged_robot.py:80-104
     Env *e = (Env *)ctx;

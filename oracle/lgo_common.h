@@ -46,10 +46,11 @@ struct Env {
     // state (host)
     std::vector<float> root, dof, contact, torques, actions, obs, rew, commands, last_actions, last_dof_vel,
         last_root_vel, feet_air_time, episode_sums, base_lin_vel, base_ang_vel, proj_grav, heights,
-        env_origins, lstm_h, lstm_c, friction, base_mass_delta, extras_episode, extras_terrain_level, inj_u;
+        env_origins, lstm_h, lstm_c, friction, base_mass_delta, extras_episode, extras_terrain_level, extras_episode_acc, inj_u;
     std::vector<uint8_t> reset, time_out, last_contacts, extras_time_outs, fault;
     std::vector<int64_t> ep_len, terrain_levels, terrain_types, inj_levels;
-    std::vector<int32_t> n_reset;
+    std::vector<int32_t> n_reset, n_fault;
+    std::vector<int64_t> fault_total;
     int64_t step_counter = 0;
     int init_done = 1, inject = 0;
 };
@@ -58,5 +59,6 @@ void compute_torques(Env &e);
 void simulate(Env &e);
 void post_physics_step(Env &e);
 void reset_all(Env &e);
+void reset_ids(Env &e, const int32_t *ids, int n);
 
 }  // namespace lgo

@@ -232,7 +232,7 @@ void post_physics_step(Env &e) {
     const int N = e.N, A = e.A, B = e.B, O = e.O;
     e.step_counter += 1;                                              // LR:115
     const bool push_now = c.push_robots && c.push_interval > 0 && (e.step_counter % c.push_interval == 0);
-    std::vector<uint8_t> was_reset(N, 0);
+    std::vector<uint8_t> was_reset(N, 0), was_fault(N, 0);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
         float *r = &e.root[(size_t)i * 13];
@@ -266,7 +266,7 @@ void post_physics_step(Env &e) {
         // ---- check_termination LR:139-145
         bool rst = false;
         for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
-        if (e.fault[i]) { rst = true; e.fault[i] = 0; }              // physics fault guard (lgo_physics.cpp)
+        if (e.fault[i]) { rst = true; e.fault[i] = 0; was_fault[i] = 1; }   // physics fault guard (lgo_physics.cpp)
         bool to = e.ep_len[i] > c.max_episode_length;
         e.time_out[i] = to;
         e.reset[i] = rst || to;
@@ -297,6 +297,10 @@ void post_physics_step(Env &e) {
     int n_reset = 0;
     for (int i = 0; i < N; ++i) n_reset += was_reset[i];
     e.n_reset[0] = n_reset;
+    int n_fault = 0;
+    for (int i = 0; i < N; ++i) n_fault += was_fault[i];
+    e.n_fault[0] = n_fault;
+    e.fault_total[0] += n_fault;
     if (n_reset > 0) {
         for (int k = 0; k < LG_NUM_REWARDS; ++k) {
             if (c.rew_scale[k] == 0.0f) { e.extras_episode[k] = 0.0f; continue; }
@@ -315,6 +319,9 @@ void post_physics_step(Env &e) {
         }
         if (c.send_timeouts) std::memcpy(e.extras_time_outs.data(), e.time_out.data(), N);
     }
+    for (int k = 0; k < LG_NUM_REWARDS; ++k) e.extras_episode_acc[k] += e.extras_episode[k];   // rsl_rl log(): mean over the steps
+    e.extras_episode_acc[LG_NUM_REWARDS] += e.extras_terrain_level[0];
+    e.extras_episode_acc[LG_NUM_REWARDS + 1] += 1.0f;
     // ---- compute_observations LR:208-226, clip LR:100-103, bookkeeping LR:132-134
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
@@ -357,6 +364,27 @@ void reset_all(Env &e) {
         for (int k = 0; k < LG_NUM_REWARDS; ++k) e.episode_sums[(size_t)k * e.N + i] = 0.0f;
         reset_env(e, i);
     }
+}
+
+// LR:147-187 called with a caller-given id list (what play / data-collection style callers do)
+void reset_ids(Env &e, const int32_t *ids, int n) {
+    const lg_cfg &c = e.cfg;
+    if (n == 0) return;                                               // LR:156-157
+    for (int k = 0; k < LG_NUM_REWARDS; ++k) {
+        if (c.rew_scale[k] == 0.0f) { e.extras_episode[k] = 0.0f; continue; }
+        float s = 0.0f;
+        for (int q = 0; q < n; ++q) { s += e.episode_sums[(size_t)k * e.N + ids[q]]; e.episode_sums[(size_t)k * e.N + ids[q]] = 0.0f; }
+        e.extras_episode[k] = (s / (float)n) / c.episode_length_s;
+    }
+    for (int q = 0; q < n; ++q) reset_env(e, ids[q]);
+    if (c.curriculum) {
+        float s = 0.0f;
+        for (int i = 0; i < e.N; ++i) s += (float)e.terrain_levels[i];
+        e.extras_terrain_level[0] = s / (float)e.N;
+    }
+    if (c.send_timeouts) std::memcpy(e.extras_time_outs.data(), e.time_out.data(), e.N);
+    e.n_reset[0] = n;
+    e.n_fault[0] = 0;
 }
 
 // ---------------------------------------------------------------- torque laws

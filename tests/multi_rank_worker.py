@@ -1,0 +1,70 @@
+"""One rank of the product multi-GPU path (not a test module: started by tests/test_hip_multi_rank.py, one fresh process
+per rank, RANK / WORLD_SIZE / MASTER_* in the environment as torch.distributed.run exports them).
+
+Every rank shares cuda:0 and the collective runs over gloo -- the one-GPU rehearsal of what bench.py / scripts/train.py do
+over RCCL with one GPU per rank.  The rank builds its env shard through task_registry.make_env(rank=, world_size=), trains
+the real OnPolicyRunner for a few iterations and writes what the parent asserts on to <outdir>/rank<r>.npz.
+
+    python tests/multi_rank_worker.py <outdir> <task> <envs_per_rank> <iterations>
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def build(task, n, rank, world, comm=None, log_dir=None):
+    """env shard + runner of one rank, identical for the process-per-rank run and the in-process emulation."""
+    from legged_gym_dev_amd.envs import task_registry
+    from legged_gym_dev_amd.utils import get_args
+    from legged_gym_dev_amd.utils.helpers import class_to_dict
+    from legged_gym_dev_amd.rl.runner import OnPolicyRunner
+    import copy
+    args = get_args(["--task", task, "--num_envs", str(n), "--headless"])
+    args.sim_device = args.rl_device = "cuda:0"
+    env_cfg, train_cfg = task_registry.get_cfgs(task)
+    env_cfg, train_cfg = copy.deepcopy(env_cfg), copy.deepcopy(train_cfg)
+    env_cfg.env.num_envs = n
+    if hasattr(env_cfg.terrain, "num_rows") and env_cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+        env_cfg.terrain.num_rows, env_cfg.terrain.num_cols, env_cfg.terrain.border_size = 3, 4, 5
+        env_cfg.terrain.max_init_terrain_level = 2
+    train_cfg.policy.actor_hidden_dims = [64, 32]
+    train_cfg.policy.critic_hidden_dims = [64, 32]
+    env, _ = task_registry.make_env(name=task, args=args, env_cfg=env_cfg, rank=rank, world_size=world)
+    torch.manual_seed(1234)                              # nn.Linear initialisation of HipPPO: any value, broadcast from rank 0 anyway
+    runner = OnPolicyRunner(env, class_to_dict(train_cfg), log_dir, device="cuda:0", comm=comm)
+    return env, runner
+
+
+def snapshot(env, runner):
+    t = env.core.t
+    return dict(params=runner.ppo.t["params"][: runner.ppo.num_params].cpu().numpy(),
+                adam_m=runner.ppo.t["adam_m"][: runner.ppo.num_params].cpu().numpy(),
+                lr=np.float64(runner.ppo.learning_rate),
+                friction=t["friction"].cpu().numpy(), base_mass_delta=t["base_mass_delta"].cpu().numpy(),
+                env_origins=t["env_origins"].cpu().numpy(), obs=t["obs"].cpu().numpy(),
+                commands=t["commands"].cpu().numpy(), root_states=t["root_states"].cpu().numpy(),
+                episode_length=t["episode_length"].cpu().numpy(), env_offset=np.int64(env.setup.env_offset),
+                adv_mean=runner.ppo.t["stats"][6].cpu().numpy(), fault_total=t["fault_total"].cpu().numpy())
+
+
+def main():
+    outdir, task, n, iters = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo")
+    env, runner = build(task, n, rank, world)
+    assert runner.world_size == world and runner.rank == rank
+    runner.learn(iters, init_at_random_ep_len=False)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **snapshot(env, runner))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""GPU: the multi-GPU path of the PRODUCT code on a one-GPU box.
+
+Two fresh processes (tests/multi_rank_worker.py), rank 0 and 1 of world 2, share cuda:0 and reduce over gloo: each builds
+its env shard with task_registry.make_env(rank=, world_size=) and trains the real OnPolicyRunner.  Checked: the ranks hold
+different env shards (constants, origins, observations), identical parameters bit for bit after training, and the same
+parameters as an in-process emulation in which the two ranks are threads and the all-reduce is an explicit sum
+(tolerance: the kernels accumulate with float atomics, so two runs of one rank already differ in the last bits).
+bench.py's own launcher (`python bench.py --gpus 2`, no torchrun) is exercised the same way.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(outdir, task, n, iters, world=2):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multi_rank_worker.py"), str(outdir), task,
+                                       str(n), str(iters)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    return [dict(np.load(os.path.join(outdir, f"rank{r}.npz"))) for r in range(world)]
+
+
+class _ThreadComm:
+    """Ranks as threads of this process; all_reduce = explicit sum of the ranks' buffers.  While the runners are being
+    constructed (one after the other, on the main thread: construction draws from the process-wide CPU generators) the
+    initial broadcast is a direct copy from rank 0's parameters."""
+
+    def __init__(self, rank, shared):
+        self.rank, self.world_size, self.sh = rank, shared["world"], shared
+
+    def all_reduce(self, t):
+        torch.cuda.synchronize()
+        self.sh["bufs"][self.rank] = t
+        self.sh["barrier"].wait()
+        if self.rank == 0:
+            bufs = self.sh["bufs"]
+            tot = bufs[0].clone()
+            for b in bufs[1:]:
+                tot += b
+            for b in bufs:
+                b.copy_(tot)
+            torch.cuda.synchronize()
+        self.sh["barrier"].wait()
+
+    def broadcast(self, t, src=0):
+        assert self.sh["phase"] == "build" and src == 0
+        if self.rank == 0:
+            self.sh["src"] = t
+        else:
+            t.copy_(self.sh["src"])
+        torch.cuda.synchronize()
+
+
+def _emulate(task, n, iters, world=2):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multi_rank_worker as w
+    shared = {"world": world, "bufs": [None] * world, "barrier": threading.Barrier(world), "phase": "build"}
+    built = [w.build(task, n, r, world, comm=_ThreadComm(r, shared)) for r in range(world)]
+    shared["phase"] = "learn"
+    errs = []
+
+    def learn(r):
+        try:
+            torch.cuda.set_device(0)
+            built[r][1].learn(iters, init_at_random_ep_len=False)
+            torch.cuda.synchronize()
+        except BaseException as e:          # noqa: BLE001
+            errs.append(e)
+            shared["barrier"].abort()
+    ths = [threading.Thread(target=learn, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(600)
+    if errs:
+        raise errs[0]
+    snaps = [w.snapshot(*built[r]) for r in range(world)]
+    for env, runner in built:
+        env.close()
+        runner.ppo.close()
+    return snaps
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough"])
+def test_two_rank_runner_over_gloo(task, tmp_path):
+    n, iters = 64, 2
+    ranks = _run_ranks(tmp_path, task, n, iters)
+    a, b = ranks
+    # disjoint shards: env offsets, constants, Philox streams
+    assert int(a["env_offset"]) == 0 and int(b["env_offset"]) == n
+    assert not np.array_equal(a["friction"], b["friction"])
+    assert not np.array_equal(a["base_mass_delta"], b["base_mass_delta"]) or task == "anymal_c_rough"
+    assert not np.array_equal(a["env_origins"], b["env_origins"])
+    assert not np.array_equal(a["obs"], b["obs"]) and not np.array_equal(a["commands"], b["commands"])
+    # one policy: identical on both ranks, bit for bit (parameters, Adam state, KL-adapted learning rate, advantage mean)
+    np.testing.assert_array_equal(a["params"], b["params"])
+    np.testing.assert_array_equal(a["adam_m"], b["adam_m"])
+    assert float(a["lr"]) == float(b["lr"]) and float(a["adv_mean"]) == float(b["adv_mean"])
+    assert np.isfinite(a["params"]).all() and int(a["fault_total"][0]) == 0 and int(b["fault_total"][0]) == 0
+    # same result as the in-process emulation (ranks = threads, all_reduce = explicit sum)
+    emu = _emulate(task, n, iters)
+    np.testing.assert_array_equal(emu[0]["params"], emu[1]["params"])
+    for r in range(2):                                    # the shards themselves are reproduced exactly
+        for key in ("friction", "base_mass_delta", "env_origins"):
+            np.testing.assert_array_equal(emu[r][key], ranks[r][key], err_msg=f"rank {r} {key}")
+    d = np.abs(emu[0]["params"] - a["params"])
+    rel = np.linalg.norm(emu[0]["params"] - a["params"]) / np.linalg.norm(a["params"])
+    assert rel < 2e-4, rel
+    # element-wise: rtol 2e-4 / atol 2 x lr x updates (an Adam step on a near-zero gradient is a sign step of size lr)
+    bad = d > 2e-4 * np.abs(a["params"]) + 2.0 * float(a["lr"]) * 1.0
+    assert bad.mean() < 5e-3, bad.mean()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun): the parent starts one child per rank before it has
+    made any GPU call; rank 0 prints the JSON line with n_gpus = 2.  Both ranks on cuda:0 over gloo here."""
+    env = dict(os.environ, LG_BENCH_BACKEND="gloo", LG_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--num_envs", "256", "--hidden", "64,32"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["num_envs_per_gpu"] == 256
+    # a rank that dies takes the job down with a non-zero code
+    env["LG_BENCH_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--num_envs", "64", "--hidden", "64,32"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0

@@ -323,3 +323,52 @@ def test_two_rank_update_equals_single_process_update():
         one.close()
         for s in sh:
             s.close()
+
+
+def test_device_randperm_is_a_permutation():
+    """mini_batch_generator's randperm, drawn by k_randperm (keyed Feistel bijection + cycle walking): every update's
+    index list is a permutation of range(T*N), differs from the previous update's, is not the identity, and is reused
+    unchanged by all epochs of that update."""
+    for N, T in ((64, 24), (4096, 24), (100, 7)):
+        hip, _, _ = _make(N, 48, 12, T, policy=dict(POLICY, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32]),
+                          alg=dict(ALG, num_mini_batches=4 if (N * T) % 4 == 0 else 1))
+        try:
+            n = (N * T // hip.cfg.num_mini_batches) * hip.cfg.num_mini_batches
+            seen = []
+            for u in range(3):
+                hip._call("begin_update")
+                torch.cuda.synchronize()
+                p = hip.t["perm"][:n].cpu().numpy().copy()
+                assert np.array_equal(np.sort(p), np.arange(n)), (N, T, u)
+                assert not np.array_equal(p, np.arange(n))
+                assert (p[1:] - p[:-1] == 1).mean() < 0.01          # no long identity runs
+                for q in seen:
+                    assert (p == q).mean() < 0.01
+                seen.append(p)
+                hip._call("minibatch_backward", 0, 0)
+                hip._call("minibatch_step")
+                torch.cuda.synchronize()
+                assert np.array_equal(hip.t["perm"][:n].cpu().numpy(), p)  # epochs reuse it
+                hip._call("end_update")
+        finally:
+            hip.close()
+
+
+def test_fewer_envs_than_action_dims():
+    """play.py's single-env path: with N < A the sigma the rollout was sampled with must still be recorded for all A action
+    dimensions (it feeds the KL term of the update), and the update stays finite."""
+    N, O, A, T = 4, 48, 12, 6
+    hip, _, _ = _make(N, O, A, T, policy=dict(POLICY, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32]), alg=dict(ALG, num_mini_batches=1))
+    try:
+        g = torch.Generator(device="cuda").manual_seed(2)
+        for t in range(T):
+            hip.act(torch.randn(N, O, device="cuda", generator=g))
+            hip.process_env_step(torch.randn(N, device="cuda", generator=g), torch.zeros(N, dtype=torch.uint8, device="cuda"), {})
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(hip.t["sigma"].cpu().numpy(), hip.param_views["std"].cpu().numpy())
+        hip.compute_returns(torch.randn(N, O, device="cuda", generator=g))
+        hip.update()
+        st = hip.stats()
+        assert np.isfinite(st["kl"]) and st["lr"] > 1e-5 * 1.01 and bool(torch.isfinite(hip.t["params"]).all())
+    finally:
+        hip.close()
