@@ -11,7 +11,7 @@ void lg_set_error(const std::string &s);
 
 extern "C" {
 void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s);
-void ppok_gemm_dx(const GemmArgs *g, int nz, const int *ldb_planes, hipStream_t s);
+void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s);
 void ppok_sync_planes(const PpoDev *P, hipStream_t s);
 int ppok_mlp_fwd(const MlpArgs *g, int mask, hipStream_t s);
 void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s);
@@ -135,13 +135,15 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
                 Net &n = p->net[z];
                 g.A[z] = n.dz[l + 1]; g.lda[z] = n.dims[l + 1];
                 g.B[z] = p->dev.params + n.w_off[l]; g.ldb[z] = n.dims[l];
+                g.Bpl[z] = p->dev.wpl + n.pl_off[l];         // current inside an update (begin_update / k_opt_adam keep them)
                 g.C[z] = n.dz[l]; g.ldc[z] = n.dims[l];
                 g.aux[z] = n.act[l]; g.ldaux[z] = n.dims[l];
                 g.colsum[z] = p->dev.grads + n.b_off[l - 1];
                 g.M[z] = M; g.N[z] = n.dims[l]; g.K[z] = n.dims[l + 1];
             }
             g.elu = p->act_code;                         // derivative of the hidden activation, through its output act[l]
-            ppok_gemm_dx(&g, 2, nullptr, p->stream);
+            g.pl_stride = p->dev.pl_stride;
+            ppok_gemm_dx(&g, 2, p->stream);
         }
     }
     if (p->overlap) {                                // join: the optimiser step (main stream) needs every dW

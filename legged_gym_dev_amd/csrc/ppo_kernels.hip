@@ -305,42 +305,111 @@ __device__ __forceinline__ void stage_store_pl(unsigned char *__restrict__ lds, 
     }
 }
 
-template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false, bool B_PL = false>
+// B operand from the SAME weight planes when the reduction runs over the planes' ROWS (input gradient: dz . W with W [k][n],
+// n contiguous): the k-tile is staged as it lies in memory -- [32 k-rows][BN n-columns] bf16 per plane, plain 16-byte copies --
+// and the fragments (8 consecutive k for one n per lane) come out of gfx950's transposing LDS read, two
+// ds_read_b64_tr_b16 (4 k x 16 n each per 16-lane group) per operand.  Image: 8-row x 32-column subtiles of 512 B with the
+// chunk XOR of cdna_hip_programming.md T10 image (a): off(row, ch) = GRP (row>>3) + 512 (ch>>2) + 64 (row&7) +
+// 16 ((ch&3) ^ ((row>>2)&3)), ch = 16-byte chunk of the row, GRP = 512 BN/32 -- conflict-free for both the b128 stores'
+// rows and the transposed reads.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int BN>
+__device__ __forceinline__ int plt_off(int row, int ch) {
+    return (BN / 32 * 512) * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+template <int BN>
+constexpr int plt_plane_bytes() { return BK * BN * 2; }
+
+template <int BN, int NT>
+__device__ __forceinline__ void stage_load_plt(const uint16_t *__restrict__ src, int64_t pl_stride, int ld, int n0, int red0, int ncols,
+                                               int nred, uint4 (&regs)[BK * BN / 8 * 3 / NT], unsigned &mask) {
+    constexpr int CPR = BN / 8, NV = BK * CPR * 3 / NT;         // chunks per row; chunks per thread
+    mask = 0u;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = threadIdx.x + v * NT;
+        const int pl = c / (BK * CPR), k = (c / CPR) % BK, ch = c % CPR;
+        const int gk = red0 + k, gn = n0 + 8 * ch;
+        const int kc_ = min(gk, nred - 1), nc_ = min(gn, ncols - 8);      // ncols % 8 == 0 (checked by the launcher)
+        regs[v] = *reinterpret_cast<const uint4 *>(src + pl * pl_stride + (size_t)kc_ * ld + nc_);
+        mask |= (gk < nred && gn < ncols) ? (1u << v) : 0u;
+    }
+}
+template <int BN, int NT>
+__device__ __forceinline__ void stage_store_plt(unsigned char *__restrict__ lds, const uint4 (&regs)[BK * BN / 8 * 3 / NT], unsigned mask) {
+    constexpr int CPR = BN / 8, NV = BK * CPR * 3 / NT;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int c = threadIdx.x + v * NT;
+        const int pl = c / (BK * CPR), k = (c / CPR) % BK, ch = c % CPR;
+        const bool in = (mask >> v) & 1u;
+        const uint4 x = in ? regs[v] : make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4 *>(lds + pl * plt_plane_bytes<BN>() + plt_off<BN>(k, ch)) = x;
+    }
+}
+__device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)p);
+}
+
+template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false, int B_PL = 0>
 __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
                                                  int M, int N, int k_begin, int k_end, unsigned char *__restrict__ lds, int wm, int wn, int li,
                                                  int lk, f32x16 (&acc)[TM][TN], const uint16_t *__restrict__ Bpl = nullptr,
                                                  int64_t pl_stride = 0) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
-    constexpr int APL = x6_plane_bytes<BM>(), BPL = x6_plane_bytes<BN>();
+    constexpr int APL = x6_plane_bytes<BM>(), BPL = B_PL == 2 ? plt_plane_bytes<BN>() : x6_plane_bytes<BN>();
     constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;
     // two register sets: the global loads of k-tile t+2 are issued before the MFMAs of tile t, and tile
     // t+1 (already landed) is split and stored after them -- one full iteration to cover the L2/HBM latency
-    constexpr int NVP = B_PL ? BN * 12 / NT : 1;
+    constexpr int NVP = B_PL ? BN * 12 / NT : 1;                 // 16-byte chunks of a plane k-tile per thread (either plane layout)
     float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
     uint4 pb0[NVP], pb1[NVP];
     unsigned ma0, mb0, ma1 = 0, mb1 = 0;
     unsigned char *lds_b = lds + 3 * APL;
     stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin, M, k_end, ra0, ma0);
-    if constexpr (B_PL) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, pb0, mb0);
+    if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, pb0, mb0);
+    else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, pb0, mb0);
     else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
     if (k_begin + BK < k_end) {
         stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin + BK, M, k_end, ra1, ma1);
-        if constexpr (B_PL) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin + BK, N, k_end, pb1, mb1);
+        if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin + BK, N, k_end, pb1, mb1);
+        else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin + BK, N, k_end, pb1, mb1);
         else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
     }
     stage_store_x6<A_RC, BM, NT, FULL>(lds, ra0, ma0);
-    if constexpr (B_PL) stage_store_pl<BN, NT>(lds_b, pb0, mb0);
+    if constexpr (B_PL == 2) stage_store_plt<BN, NT>(lds_b, pb0, mb0);
+    else if constexpr (B_PL == 1) stage_store_pl<BN, NT>(lds_b, pb0, mb0);
     else stage_store_x6<B_RC, BN, NT, FULL>(lds_b, rb0, mb0);
     __syncthreads();
     // fragment of tile a, plane p, k-step s: base + a*8*X6_ROWB (32 logical rows = 8 physical) + p*PL + s*32
     const unsigned char *fa = lds + x6_prow<BM>(wm + li) * X6_ROWB + 16 * lk;
     const unsigned char *fb = lds_b + x6_prow<BN>(wn + li) * X6_ROWB + 16 * lk;
+    // transposed-read bases of this lane (B_PL == 2): group g = lane >> 4 takes n-columns 16 (g & 1) .. +15 and k-rows
+    // 8 (g >> 1) + 4 h .. +3 of a k-step; lane 4 q + p of the group addresses row q, half-chunk p (T10)
+    const int tg = (threadIdx.x >> 4) & 3, tq = (threadIdx.x >> 2) & 3, tp = threadIdx.x & 3;
+    const unsigned char *ft[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        ft[h] = lds_b + (BN / 32 * 512) * (tg >> 1) + 512 * (wn / 32) + 64 * (4 * h + tq) +
+                16 * ((2 * (tg & 1) + (tp >> 1)) ^ (2 * (tg >> 1) + h)) + 8 * (tp & 1);
+    auto read_b = [&](int b, int p, int s) -> bf16x8 {
+        if constexpr (B_PL == 2) {
+            const int o = 512 * b + p * BPL + (BN / 32 * 512) * 2 * s;
+            const s16x4 lo = lds_read_tr16(ft[0] + o), hi = lds_read_tr16(ft[1] + o);
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            return *reinterpret_cast<const bf16x8 *>(fb + b * 8 * X6_ROWB + p * BPL + s * 32);
+        }
+    };
 
     auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], uint4 (&xp)[NVP], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA],
                     float4 (&yb)[NVB], uint4 (&yp)[NVP], unsigned &yma, unsigned &ymb) {
         if (k0 + 2 * BK < k_end) {
             stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k0 + 2 * BK, M, k_end, ya, yma);
-            if constexpr (B_PL) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k0 + 2 * BK, N, k_end, yp, ymb);
+            if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k0 + 2 * BK, N, k_end, yp, ymb);
+            else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k0 + 2 * BK, N, k_end, yp, ymb);
             else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
         }
         bf16x8 av[2][TM][3], bv[2][TN][3];
@@ -351,7 +420,7 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bv[0][b][p] = *reinterpret_cast<const bf16x8 *>(fb + b * 8 * X6_ROWB + p * BPL);
+            for (int p = 0; p < 3; ++p) bv[0][b][p] = read_b(b, p, 0);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             if (s + 1 < BK / 16) {
@@ -364,7 +433,7 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        bv[(s + 1) & 1][b][p] = *reinterpret_cast<const bf16x8 *>(fb + b * 8 * X6_ROWB + p * BPL + (s + 1) * 32);
+                        bv[(s + 1) & 1][b][p] = read_b(b, p, s + 1);
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
@@ -384,7 +453,8 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
         __syncthreads();                         // every wave is done reading before the tile is refilled
         if (k0 + BK < k_end) {
             stage_store_x6<A_RC, BM, NT, FULL>(lds, xa, xma);
-            if constexpr (B_PL) stage_store_pl<BN, NT>(lds_b, xp, xmb);
+            if constexpr (B_PL == 2) stage_store_plt<BN, NT>(lds_b, xp, xmb);
+            else if constexpr (B_PL == 1) stage_store_pl<BN, NT>(lds_b, xp, xmb);
             else stage_store_x6<B_RC, BN, NT, FULL>(lds_b, xb, xmb);
         }
         __syncthreads();
@@ -477,9 +547,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, i
     }
 }
 
-template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, bool B_PL = false>
+template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, int B_PL = 0>
 __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) : 1) k_gemm(GemmArgs g) {
-    static_assert(!B_PL || (X6 && B_RC), "weight planes feed the split-bf16 mainloop as a reduction-contiguous operand");
+    static_assert(B_PL == 0 || (X6 && (B_PL == 1) == B_RC), "weight planes feed the split-bf16 mainloop: [n][k] planes as the reduction-"
+                  "contiguous operand (1), the same planes read along their rows through the transposing LDS read (2)");
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;       // WGM x WGN waves, each TM x TN tiles of 32x32
     static_assert(X6 || (WGM == 2 && WGN == 2), "the fp32-input mainloop is written for 2x2 waves");
     const int z = blockIdx.z;
@@ -504,7 +575,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
     const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (((B_RC ? k_end : N) & 3) == 0) && (B_RC ? k_end : N) >= 4;
 
     constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
-    constexpr int LDS_BYTES = X6 ? 3 * (x6_plane_bytes<BM>() + x6_plane_bytes<BN>()) : (DBUF ? 2 : 1) * (AF + BF) * 4;
+    constexpr int LDS_BYTES = X6 ? 3 * (x6_plane_bytes<BM>() + (B_PL == 2 ? plt_plane_bytes<BN>() : x6_plane_bytes<BN>()))
+                                 : (DBUF ? 2 : 1) * (AF + BF) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     float *lds = reinterpret_cast<float *>(lds_raw);
 
@@ -524,9 +596,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
         // whole tile in range in all three dimensions (workgroup-uniform): staging without clamps and masks
         const bool full = a_vec && b_vec && m0 + BM <= M && n0 + BN <= N && ((k_end - k_begin) % BK) == 0;
         if (B_PL) {
-            if (full) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
-            else if (a_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, false, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
-            else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false, false, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            const bool fullp = a_vec && m0 + BM <= M && n0 + BN <= N && ((k_end - k_begin) % BK) == 0;
+            if (fullp) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true, B_PL>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            else if (a_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, false, B_PL>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false, false, B_PL>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
         } else
         if (full) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
         else if (a_vec && b_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
@@ -556,7 +629,7 @@ static int g_gemm_t96 = 0;     // 96x128 tile where it fills the 512 workgroup s
                                // (the side stream's weight-gradient GEMMs already fill the idle slots); kept for A/B
 extern "C" void ppok_debug_set_t96(int v) { g_gemm_t96 = v; }
 
-template <int EPI>
+template <int EPI, bool B_RC = true, int PL = 1>
 static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
     int maxM = 0, maxN = 0;
     for (int z = 0; z < nz; ++z) { maxM = g.M[z] > maxM ? g.M[z] : maxM; maxN = g.N[z] > maxN ? g.N[z] : maxN; }
@@ -568,14 +641,14 @@ static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
         const double c128 = (double)((big_tiles * nz + 511) / 512), c96 = 0.75 * (double)((t96 * nz + 511) / 512);
         if (g_gemm_t96 && c96 < c128) {
             dim3 grid((unsigned)t96, 1, nz);
-            hipLaunchKernelGGL((k_gemm<true, true, EPI, 3, 1, false, true, 1, 4, true>), grid, dim3(256), 0, s, g);
+            hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 3, 1, false, true, 1, 4, PL>), grid, dim3(256), 0, s, g);
         } else {
             dim3 grid((unsigned)big_tiles, 1, nz);
-            hipLaunchKernelGGL((k_gemm<true, true, EPI, 2, 1, false, true, 2, 4, true>), grid, dim3(512), 0, s, g);
+            hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 2, 1, false, true, 2, 4, PL>), grid, dim3(512), 0, s, g);
         }
     } else {
         dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), 1, nz);
-        hipLaunchKernelGGL((k_gemm<true, true, EPI, 1, 1, false, true, 2, 2, true>), grid, dim3(256), 0, s, g);
+        hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 1, 1, false, true, 2, 2, PL>), grid, dim3(256), 0, s, g);
     }
 }
 static bool planes_ok(const GemmArgs &g, int nz) {
@@ -603,17 +676,22 @@ static void launch_gemm(const GemmArgs &g, int nz, int splits, hipStream_t s) {
         else hipLaunchKernelGGL((k_gemm<A_RC, B_RC, EPI, 1, 1, true>), grid, dim3(256), 0, s, g);
     }
 }
-// g->Bpl (optional): bf16 planes of W [n][k]; the caller passes both B (fp32 W) and Bpl, whichever path is eligible is
-// taken.  (Planes of W^T for the input gradient were measured too: the scattered 2-byte stores that keep them current in
-// the optimiser kernel cost what they saved in the GEMM; ppok_gemm_dx keeps the hook, the caller passes none.)
+// planes read along their rows (input gradient): column count and leading dimension in whole 16-byte chunks
+static bool planes_t_ok(const GemmArgs &g, int nz) {
+    if (!g_gemm_planes || !g_gemm_x6) return false;
+    for (int z = 0; z < nz; ++z)
+        if (!g.Bpl[z] || (g.ldb[z] & 7) || (g.N[z] & 7) || g.N[z] < 8 || ((uintptr_t)g.Bpl[z] & 15) || (g.pl_stride & 7)) return false;
+    return true;
+}
+// g->Bpl (optional): bf16 planes of W [n_out][n_in] kept by the optimiser step; the caller passes both B (fp32 W) and Bpl,
+// whichever path is eligible is taken.  Forward: the planes are the reduction-contiguous operand.  Input gradient: the
+// SAME planes, reduced over their rows through the transposing LDS read (no second image of W^T to keep current).
 extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) {
     if (planes_ok(*g, nz)) launch_gemm_pl<0>(*g, nz, s);
     else launch_gemm<true, true, 0>(*g, nz, 1, s);
 }
-extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, const int *ldb_planes, hipStream_t s) {
-    GemmArgs h = *g;
-    if (ldb_planes) { for (int z = 0; z < nz; ++z) h.ldb[z] = ldb_planes[z]; }
-    if (ldb_planes && planes_ok(h, nz)) launch_gemm_pl<1>(h, nz, s);
+extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s) {
+    if (planes_t_ok(*g, nz)) launch_gemm_pl<1, false, 2>(*g, nz, s);
     else launch_gemm<true, false, 1>(*g, nz, 1, s);
 }
 extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s) { launch_gemm<false, false, 2>(*g, nz, splits, s); }
@@ -1256,4 +1334,34 @@ extern "C" void ppok_debug_gemm(const float *A, const float *B, float *C, int M,
     if (mode == 0) { g.lda[0] = K; g.ldb[0] = K; launch_gemm<true, true, 0>(g, 1, 1, (hipStream_t)stream); }
     else if (mode == 1) { g.lda[0] = K; g.ldb[0] = N; g.aux[0] = C; g.ldaux[0] = N; g.elu = 1; launch_gemm<true, false, 1>(g, 1, 1, (hipStream_t)stream); }
     else { g.lda[0] = M; g.ldb[0] = N; launch_gemm<false, false, 2>(g, 1, splits, (hipStream_t)stream); }
+}
+
+// Debug entry for the weight-plane operand paths: W [rows][cols] fp32 is split into its three bf16 planes (caller-provided
+// scratch of 3 x plane_stride uint16, plane_stride = rows * cols rounded up to 8), then
+//   mode 0: C[M][rows] = A[M][cols] . W^T   (forward: planes as the reduction-contiguous operand)
+//   mode 1: C[M][cols] = A[M][rows] . W     (input gradient: the same planes through the transposing LDS read)
+__global__ void __launch_bounds__(256) k_debug_split(const float *__restrict__ W, uint16_t *__restrict__ pl, int64_t n, int64_t stride) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h, m, l;
+        split2(W[k], 0.f, h, m, l);
+        pl[k] = (uint16_t)h; pl[stride + k] = (uint16_t)m; pl[2 * stride + k] = (uint16_t)l;
+    }
+}
+extern "C" int ppok_debug_gemm_planes(const float *A, const float *W, float *C, uint16_t *planes, int64_t plane_stride, int M, int rows,
+                                      int cols, int mode, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_debug_split, dim3(256), dim3(256), 0, s, W, planes, (int64_t)rows * cols, plane_stride);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A[0] = A; g.B[0] = W; g.C[0] = C; g.M[0] = M; g.Bpl[0] = planes; g.pl_stride = plane_stride; g.ldb[0] = cols;
+    if (mode == 0) {
+        g.N[0] = rows; g.K[0] = cols; g.lda[0] = cols; g.ldc[0] = rows;
+        if (!planes_ok(g, 1)) return -1;
+        launch_gemm_pl<0>(g, 1, s);
+    } else {
+        g.N[0] = cols; g.K[0] = rows; g.lda[0] = rows; g.ldc[0] = cols; g.aux[0] = C; g.ldaux[0] = cols; g.elu = 0;
+        if (!planes_t_ok(g, 1)) return -1;
+        launch_gemm_pl<1, false, 2>(g, 1, s);
+    }
+    return 0;
 }

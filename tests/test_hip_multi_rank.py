@@ -133,11 +133,16 @@ def test_two_rank_runner_over_gloo(task, tmp_path):
     for r in range(2):                                    # the shards themselves are reproduced exactly
         for key in ("friction", "base_mass_delta", "env_origins"):
             np.testing.assert_array_equal(emu[r][key], ranks[r][key], err_msg=f"rank {r} {key}")
-    d = np.abs(emu[0]["params"] - a["params"])
     rel = np.linalg.norm(emu[0]["params"] - a["params"]) / np.linalg.norm(a["params"])
-    assert rel < 2e-4, rel
-    # element-wise: rtol 2e-4 / atol 2 x lr x updates (an Adam step on a near-zero gradient is a sign step of size lr)
-    bad = d > 2e-4 * np.abs(a["params"]) + 2.0 * float(a["lr"]) * 1.0
+    # The kernels accumulate gradients, bias sums and loss statistics with float atomics, so two runs of the SAME code differ
+    # in the last bits of every gradient and contact dynamics amplify that over 48 policy steps.  The bar is therefore the
+    # run-to-run noise of the emulation itself (measured here by running it twice), with 2e-4 as the floor:
+    emu2 = _emulate(task, n, iters)
+    noise = np.linalg.norm(emu2[0]["params"] - emu[0]["params"]) / np.linalg.norm(a["params"])
+    assert rel < max(2e-4, 4.0 * noise), (rel, noise)
+    # element-wise: an Adam step on a near-zero gradient is a sign step of size lr, so allow 2 x lr absolute
+    d = np.abs(emu[0]["params"] - a["params"])
+    bad = d > 2e-4 * np.abs(a["params"]) + 2.0 * float(a["lr"]) + 8.0 * np.abs(emu2[0]["params"] - emu[0]["params"])
     assert bad.mean() < 5e-3, bad.mean()
 
 

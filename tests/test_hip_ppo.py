@@ -216,6 +216,47 @@ def test_split_bf16_gemm_is_fp32_accurate(mode, M, N, K):
     assert err[1] <= bound and err[3] <= bound, err
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("M,rows,cols", [(24576, 256, 512), (4096, 128, 256), (3001, 72, 48), (1000, 512, 48), (640, 16, 128), (515, 264, 40)])
+def test_weight_plane_gemms_are_fp32_accurate(mode, M, rows, cols):
+    """The two GEMMs that take W [rows][cols] from its three bf16 planes -- forward A.W^T (planes as the reduction-contiguous
+    operand) and input gradient A.W (the SAME planes read along their rows through ds_read_b64_tr_b16) -- against a float64
+    product, beside the fp32-input MFMA kernel on the fp32 W: error <= 2 x that kernel's + 2^-22 max|C| (the planes are an
+    exact split).  Shapes: the update's big interior tiles, the rollout's 64x64 tiles, ragged rows / columns / k-tails."""
+    import ctypes
+    from legged_gym_dev_amd.lib import load
+    lib = load()
+    lib.ppok_debug_gemm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    lib.ppok_debug_gemm_planes.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(M + rows + cols + mode)
+    K = cols if mode == 0 else rows
+    scale = torch.exp2(torch.randint(-12, 12, (K,), device="cuda", generator=g).float())
+    W = torch.randn(rows, cols, device="cuda", generator=g)
+    W = W / scale if mode == 0 else W / scale[:, None]
+    A = torch.randn(M, K, device="cuda", generator=g) * scale
+    ref = A.double() @ (W.double().t() if mode == 0 else W.double())
+    N = rows if mode == 0 else cols
+    stride = (rows * cols + 7) // 8 * 8
+    planes = torch.zeros(3 * stride + 8, dtype=torch.int16, device="cuda")
+    C = torch.ones(M, N, device="cuda")
+    rc = lib.ppok_debug_gemm_planes(vp(A), vp(W), vp(C), vp(planes), stride, M, rows, cols, mode, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err_pl = float((C.double() - ref).abs().max())
+    try:
+        lib.ppok_debug_set_x6(ctypes.c_int(0))
+        C0 = torch.ones(M, N, device="cuda")
+        lib.ppok_debug_gemm(vp(A), vp(W), vp(C0), M, N, K, mode, 1, st)
+        torch.cuda.synchronize()
+        err_f32 = float((C0.double() - ref).abs().max())
+    finally:
+        lib.ppok_debug_set_x6(ctypes.c_int(3))
+    assert torch.isfinite(C).all()
+    assert err_pl <= 2.0 * err_f32 + 2.0 ** -22 * float(ref.abs().max()), (err_pl, err_f32)
+
+
 @pytest.mark.parametrize("activation", ["selu", "relu", "lrelu", "tanh", "sigmoid"])
 def test_other_activations_forward_and_gradients(activation):
     """ActorCritic `activation` values other than elu (legged_robot_config.py:244; crelu excluded): inference
