@@ -1,5 +1,6 @@
 // C-ABI (include/legged_hip.h, lg_ppo_*) for the PPO learner: parameter/storage allocation in
 // HBM, layer-by-layer GEMM scheduling of the ActorCritic forward/backward, update orchestration.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -118,7 +119,10 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         }
         // ~256 workgroups per net: enough to fill the chip, few enough that the split-M float atomics
         // (splits x output floats) stay well below the MFMA time
-        int splits = (int)((256 + tiles - 1) / tiles);
+        // workgroups per net over (output tiles x reduction splits); swept 64..384 inside the update (side stream beside the
+        // input-gradient chain): 0.637 / 0.585 / 0.597 / 0.574 / 0.560 ms per minibatch at 64 / 128 / 192 / 256 / 384
+        static const int dw_target = getenv("LG_DW_WGS") ? atoi(getenv("LG_DW_WGS")) : 384;
+        int splits = (int)((dw_target + tiles - 1) / tiles);
         int max_splits = M / 256 > 0 ? M / 256 : 1;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -184,7 +188,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->fused_act = 1;
     for (int l = 0; l < cfg->num_hidden; ++l)
         if (cfg->actor_hidden[l] > 128 || cfg->critic_hidden[l] > 128) p->fused_act = 0;
-    p->overlap = 1;
+    p->overlap = getenv("LG_PPO_OVERLAP") ? atoi(getenv("LG_PPO_OVERLAP")) : 1;
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming) != hipSuccess) {
@@ -377,7 +381,10 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     const int nl = na.nl, H3 = na.dims[nl - 1];
     // fused head (forward + loss + backward of the two thin head layers) when both nets end in the same
     // supported width; otherwise head GEMMs + k_loss
-    const bool fuse = p->act_code == 1 && nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32);   // at 128 the head GEMMs + k_loss measured faster (0.755 vs 0.773 ms)
+    // at 128 wide the fused head was 18 us slower per minibatch while the weight-gradient stream had slack; with that stream the
+    // long pole (profiles/r02_timelines.txt) it is 9 us faster than head GEMM + k_loss + two head-gradient GEMMs (A/B on one box)
+    static const int fuse128 = getenv("LG_HEAD_FUSE128") ? atoi(getenv("LG_HEAD_FUSE128")) : 1;
+    const bool fuse = p->act_code == 1 && nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32 || (H3 == 128 && fuse128));
     forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],

@@ -2,6 +2,7 @@
 // action sampling, GAE scan, PPO loss, grad-norm clip + Adam with the KL-adaptive learning rate
 // kept on the device.  Semantics: rsl_rl v1.0.2 (SURVEY.md Appendix B -- third-party, not in the
 // reference tree; call sites legged_gym/utils/task_registry.py:148-155).
+#include <cstdlib>
 #include <cstring>
 
 #include "ppo_device.h"
@@ -1309,8 +1310,10 @@ void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
 int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
                     int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c, hipStream_t s) {
     const int ntiles = (P->mb_rows + HEAD_ROWS - 1) / HEAD_ROWS;
-    dim3 grid(ntiles < HEAD_GRID ? ntiles : HEAD_GRID), block(256);
-    if (H3 == 64) hipLaunchKernelGGL((k_head_fused<64>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+    static const int head_grid = getenv("LG_HEAD_GRID") ? atoi(getenv("LG_HEAD_GRID")) : HEAD_GRID;
+    dim3 grid(ntiles < head_grid ? ntiles : head_grid), block(256);
+    if (H3 == 128) hipLaunchKernelGGL((k_head_fused<128>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+    else if (H3 == 64) hipLaunchKernelGGL((k_head_fused<64>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else if (H3 == 32) hipLaunchKernelGGL((k_head_fused<32>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else return -1;
     return 0;
