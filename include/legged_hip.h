@@ -49,7 +49,8 @@ enum lg_reward {
 /* Per-env random-draw slots.  In normal operation slot s of env e at step k is
  * Philox4x32-10(key = seed, counter = (global env id, k, s / 4, 0))[s % 4] >> 8 scaled to [0,1);
  * with lg_inject_uniforms() the value is read from the injected (N, K) buffer instead (parity
- * tests replay the reference's torch.rand draws this way).  K = LG_SLOT_NOISE(A) + num_obs. */
+ * tests replay the reference's torch.rand draws this way).  K = LG_SLOT_NOISE(A) + num_obs
+ * (LG_TSLOT_NOISE(A) + num_obs for the trajectory env). */
 #define LG_SLOT_CMD        0   /* 3: callback command resample x, y, yaw|heading (legged_robot.py:365-387) */
 #define LG_SLOT_PUSH       3   /* 2: push velocity xy (:456-461) */
 #define LG_SLOT_LEVEL      5   /* 1: terrain level when the curriculum wraps (:479-483) */
@@ -80,6 +81,78 @@ typedef struct lg_model {
     float sph_radius[LG_MAX_SPHERES];
 } lg_model;
 
+/* ---- Extra reward terms.  The reference binds ANY method named _reward_<name> of the env class to a non-zero
+ * rewards.scales.<name> (legged_robot.py:605-629; cassie.py:43-46 and legged_robot_trajectory.py:1060-1110 add terms that way).
+ * Python code cannot run inside the step kernel, so a subclass declares such a term as data: one of a few generic kinds over
+ * named per-env signals.  The term takes part in the reward sum at its alphabetical position (lg_cfg.term_order) and gets its
+ * own episode_sums / extras_episode row (LG_NUM_REWARDS + index). */
+#define LG_MAX_XTERMS 4
+#define LG_NUM_TERMS (LG_NUM_REWARDS + LG_MAX_XTERMS)
+enum lg_xterm_kind {
+    LG_XT_NONE = 0,
+    LG_XT_EXP_NEG_WSQ_ERR,     /* exp(-sum_k w[k] (a[k] - b[k])^2 / p[0])          e.g. tracking_lin_vel, tracking_rom           */
+    LG_XT_WSQ,                 /* sum_k w[k] a[k]^2                                 e.g. orientation, ang_vel_xy                  */
+    LG_XT_SLOPED_ERR_CHANGE    /* d = |(a-b)^2|_2 - |c|_2 ; (d < 0 ? p[0] : p[1]) d e.g. differential_error (c = error at reset)  */
+};
+enum lg_signal {               /* per-env vectors a term may read (length): */
+    LG_SIG_ZERO = 0, LG_SIG_BASE_LIN_VEL /*3*/, LG_SIG_BASE_ANG_VEL /*3*/, LG_SIG_PROJ_GRAVITY /*3*/, LG_SIG_COMMANDS /*4*/,
+    LG_SIG_ROOT_POS /*3*/, LG_SIG_TRAJ0 /*2: first point of the reference trajectory*/, LG_SIG_PREV_ERROR /*2*/,
+    LG_SIG_DOF_POS_REL /*A: q - default*/, LG_SIG_DOF_VEL /*A*/, LG_SIG_TORQUES /*A*/, LG_SIG_ACTIONS /*A*/, LG_SIG_LAST_ACTIONS /*A*/,
+    LG_NUM_SIGNALS
+};
+typedef struct lg_xterm {
+    int32_t kind, n;                      /* kind; vector length used (<= 8) */
+    int32_t sig_a, off_a, sig_b, off_b, sig_c, off_c;   /* signals and first component */
+    float scale;                          /* rewards.scales.<name> * dt */
+    float p[3];
+    float w[8];
+} lg_xterm;
+
+/* ---- Trajectory-tracking env variant (legged_robot_trajectory.py): the velocity commands are replaced by
+ * a reference trajectory from a reduced-order model (trajopt/rom_dynamics.py: SingleInt2D, state = xy position, input = xy
+ * velocity) driven by the random input generator TrajectoryGenerator (:441-616).  Per env the generator keeps four input
+ * laws -- sample-and-hold, ramp, extreme (v_min | 0 | v_max), sinusoid -- mixed with random weights, all redrawn when the
+ * env's hold time t_final runs out; the ROM integrates the mixed input every rom_dt, the env observes the N last points
+ * interpolated at its own time.  Pushes come from per-env timers (:150-160). */
+#define LG_TRAJ_MAX_PTS 17                /* N * dN + 1 points kept per env */
+#define LG_TG_NDRAW 20                    /* uniforms of one generator resample: const 2, ramp 2, extreme 2, sin mag/mean/freq/off
+                                             4 x 2, hold time 1, weights 4, stationary 1 */
+/* layout of one row of lg_buffers.tg_state (LG_TG_STRIDE floats per env): */
+#define LG_TG_W 0          /* 4 mixing weights */
+#define LG_TG_T_FINAL 4
+#define LG_TG_T 5
+#define LG_TG_K 6
+#define LG_TG_CONST 7      /* 2 */
+#define LG_TG_EXTREME 9    /* 2 */
+#define LG_TG_RAMP_T0 11
+#define LG_TG_RAMP_V0 12   /* 2 */
+#define LG_TG_RAMP_V1 14   /* 2 */
+#define LG_TG_SIN_MAG 16   /* 2 */
+#define LG_TG_SIN_FREQ 18  /* 2 */
+#define LG_TG_SIN_OFF 20   /* 2 */
+#define LG_TG_SIN_MEAN 22  /* 2 */
+#define LG_TG_STATIONARY 24 /* 0 | 1 */
+#define LG_TG_STRIDE 28
+typedef struct lg_traj_cfg {
+    int32_t enabled, N, dN, randomize_rom_distance;
+    float rom_dt, t_low, t_high, freq_low, freq_high, prob_stationary, zero_rom_dist_llh, max_push_vel_xy;
+    float v_min[2], v_max[2], obs_scale[2], max_rom_dist[2];
+    float push_t_lo, push_t_hi;           /* domain_rand.time_between_pushes */
+} lg_traj_cfg;
+/* uniform slots of the trajectory env (replace LG_SLOT_* when lg_cfg.traj.enabled): */
+#define LG_TSLOT_TG        0                        /* LG_TG_NDRAW: generator resample in the step callback */
+#define LG_TSLOT_PUSH      LG_TG_NDRAW              /* 2: push velocity xy */
+#define LG_TSLOT_TIMER     (LG_TG_NDRAW + 2)        /* 1: next push time */
+#define LG_TSLOT_LEVEL     (LG_TG_NDRAW + 3)
+#define LG_TSLOT_DOF       (LG_TG_NDRAW + 4)        /* A */
+#define LG_TSLOT_XY(A)     (LG_TG_NDRAW + 4 + (A))  /* 2 */
+#define LG_TSLOT_VEL(A)    (LG_TG_NDRAW + 6 + (A))  /* 6 */
+#define LG_TSLOT_ROMD(A)   (LG_TG_NDRAW + 12 + (A)) /* 3: start-offset mask draw + xy offset (:224-229) */
+#define LG_TSLOT_RTG(A)    (LG_TG_NDRAW + 15 + (A)) /* LG_TG_NDRAW: generator resample of a reset env -- or of a NON-reset env
+                                                       whose hold time ran out on a step where some env resets: the reference's
+                                                       reset loop re-checks every env (rom_dynamics.py:571-574,598-608) */
+#define LG_TSLOT_NOISE(A)  (2 * LG_TG_NDRAW + 15 + (A))
+
 /* Flattened LeggedRobotCfg (+ what _parse_cfg/_init_buffers derive from it,
  * legged_robot.py:533-603,819-837). */
 typedef struct lg_cfg {
@@ -106,6 +179,12 @@ typedef struct lg_cfg {
     float dof_vel_limits[LG_MAX_DOF], torque_limits[LG_MAX_DOF];
     float gravity[3], ground_friction;    /* ground mu; combined with the env's mu by averaging */
     float contact_offset, max_depenetration_velocity, contact_erp, _pad3;
+    int32_t num_xterms, feet_air_time_ungated /* trajectory env: no command gate (legged_robot_trajectory.py:1071-1080) */;
+    int32_t num_terms, _pad4;
+    int32_t term_order[LG_NUM_TERMS];   /* active terms (builtin id, or LG_NUM_REWARDS + xterm index) in the order the
+                                                             reference sums them (alphabetical); termination is not listed (applied last) */
+    lg_xterm xterms[LG_MAX_XTERMS];
+    lg_traj_cfg traj;
     float lstm_w[LG_LSTM_NW];             /* in_scale2 out_scale1 | w_ih0 64 w_hh0 256 b_ih0 32 b_hh0 32 |
                                              w_ih1 256 w_hh1 256 b_ih1 32 b_hh1 32 | lin_w 8 lin_b 1 */
     const float *noise_vec;               /* host, num_obs   (legged_robot.py:507-530) */
@@ -115,7 +194,7 @@ typedef struct lg_cfg {
 
 /* State tensors.  Layouts are the reference's: root (N,13) =
  * [pos3, quat xyzw, lin vel3, ang vel3] world frame; dof_state (N,A,2) = [q, qdot] interleaved;
- * contact (N,B,3) world N; episode_sums is (LG_NUM_REWARDS, N) so each term is a contiguous (N,). */
+ * contact (N,B,3) world N; episode_sums is (LG_NUM_REWARDS + LG_MAX_XTERMS, N) so each term is a contiguous (N,). */
 typedef struct lg_buffers {
     float *root_states, *dof_state, *contact_forces, *torques, *actions;
     float *obs, *rew;
@@ -130,15 +209,21 @@ typedef struct lg_buffers {
     float *friction, *base_mass_delta;    /* per-env randomised constants (legged_robot.py:259-341) */
     /* extras: filled by the step's finalize pass; episode means only change on steps where at
      * least one env resets, time_outs likewise (the reference's stale-mask quirk, :156-157,186-187) */
-    float *extras_episode;                /* LG_NUM_REWARDS */
+    float *extras_episode;                /* LG_NUM_REWARDS + LG_MAX_XTERMS */
     float *extras_terrain_level;          /* 1 */
     uint8_t *extras_time_outs;            /* N */
-    float *extras_episode_acc;            /* LG_NUM_REWARDS + 2: running sums over steps of extras_episode, of extras_terrain_level
+    float *extras_episode_acc;            /* LG_NUM_REWARDS + LG_MAX_XTERMS + 2: running sums over steps of extras_episode, of extras_terrain_level
                                              and the number of steps summed -- rsl_rl's log() averages infos["episode"] over every
                                              step of an iteration; the reader divides and clears */
     int32_t *n_reset;                     /* 1: envs reset by the last step */
     int32_t *n_fault;                     /* 1: envs the physics fault guard stopped during the last step (they are among n_reset) */
     int64_t *fault_total;                 /* 1: the same, summed since lg_create */
+    /* trajectory env (all unused otherwise): */
+    float *tg_state;                      /* (N, LG_TG_STRIDE) generator state, LG_TG_* */
+    float *tg_traj;                       /* (N, traj.N * traj.dN + 1, 2) ROM states, oldest first */
+    float *trajectory;                    /* (N, traj.N, 2) what the env observes: interpolated at the env's time (:410-411) */
+    float *prev_error;                    /* (N, 2) squared tracking error at the last reset (:199) */
+    float *push_timer;                    /* (N) time_until_next_push (:150-160) */
     float *inject_uniforms;               /* (N, K) or unused */
     int64_t *inject_levels;               /* N */
 } lg_buffers;

@@ -19,6 +19,23 @@ NUM_REWARDS = len(REWARD_NAMES)
 assert REWARD_NAMES == sorted(REWARD_NAMES)
 
 SLOT_CMD, SLOT_PUSH, SLOT_LEVEL, SLOT_DOF = 0, 3, 5, 6
+MAX_XTERMS = 4
+NUM_TERMS = NUM_REWARDS + MAX_XTERMS
+XT_EXP_NEG_WSQ_ERR, XT_WSQ, XT_SLOPED_ERR_CHANGE = 1, 2, 3
+SIGNALS = {"zero": (0, 8), "base_lin_vel": (1, 3), "base_ang_vel": (2, 3), "projected_gravity": (3, 3), "commands": (4, 4),
+           "root_pos": (5, 3), "traj0": (6, 2), "prev_error": (7, 2), "dof_pos_rel": (8, MAX_DOF), "dof_vel": (9, MAX_DOF),
+           "torques": (10, MAX_DOF), "actions": (11, MAX_DOF), "last_actions": (12, MAX_DOF)}      # name -> (lg_signal, length)
+TRAJ_MAX_PTS, TG_NDRAW, TG_STRIDE = 17, 20, 28
+TG_FIELDS = {"weights": (0, 4), "t_final": (4, 1), "t": (5, 1), "k": (6, 1), "const": (7, 2), "extreme": (9, 2),
+             "ramp_t_start": (11, 1), "ramp_v_start": (12, 2), "ramp_v_end": (14, 2), "sin_mag": (16, 2), "sin_freq": (18, 2),
+             "sin_off": (20, 2), "sin_mean": (22, 2), "stationary": (24, 1)}                        # LG_TG_* offsets
+
+
+def tslots(A):
+    """LG_TSLOT_* of the trajectory env."""
+    n = TG_NDRAW
+    return {"tg": 0, "push": n, "timer": n + 2, "level": n + 3, "dof": n + 4, "xy": n + 4 + A, "vel": n + 6 + A,
+            "romd": n + 12 + A, "rtg": n + 15 + A, "noise": 2 * n + 15 + A}
 
 
 def slot_xy(A): return 6 + A
@@ -41,6 +58,19 @@ class lg_model(C.Structure):
         ("vel_limit", f32 * MAX_DOF), ("joint_damping", f32 * MAX_DOF),
         ("body_dyn", i32 * MAX_BODIES), ("sph_link", i32 * MAX_SPHERES), ("sph_body", i32 * MAX_SPHERES),
         ("sph_center", f32 * 3 * MAX_SPHERES), ("sph_radius", f32 * MAX_SPHERES)]
+
+
+class lg_xterm(C.Structure):
+    _fields_ = [("kind", i32), ("n", i32), ("sig_a", i32), ("off_a", i32), ("sig_b", i32), ("off_b", i32), ("sig_c", i32),
+                ("off_c", i32), ("scale", f32), ("p", f32 * 3), ("w", f32 * 8)]
+
+
+class lg_traj_cfg(C.Structure):
+    _fields_ = [("enabled", i32), ("N", i32), ("dN", i32), ("randomize_rom_distance", i32),
+                ("rom_dt", f32), ("t_low", f32), ("t_high", f32), ("freq_low", f32), ("freq_high", f32), ("prob_stationary", f32),
+                ("zero_rom_dist_llh", f32), ("max_push_vel_xy", f32),
+                ("v_min", f32 * 2), ("v_max", f32 * 2), ("obs_scale", f32 * 2), ("max_rom_dist", f32 * 2),
+                ("push_t_lo", f32), ("push_t_hi", f32)]
 
 
 class lg_cfg(C.Structure):
@@ -68,6 +98,8 @@ class lg_cfg(C.Structure):
         ("dof_pos_limits", f32 * 2 * MAX_DOF), ("dof_vel_limits", f32 * MAX_DOF), ("torque_limits", f32 * MAX_DOF),
         ("gravity", f32 * 3), ("ground_friction", f32),
         ("contact_offset", f32), ("max_depenetration_velocity", f32), ("contact_erp", f32), ("_pad3", f32),
+        ("num_xterms", i32), ("feet_air_time_ungated", i32), ("num_terms", i32), ("_pad4", i32),
+        ("term_order", i32 * NUM_TERMS), ("xterms", lg_xterm * MAX_XTERMS), ("traj", lg_traj_cfg),
         ("lstm_w", f32 * LSTM_NW),
         ("noise_vec", PF), ("height_points", PF), ("terrain_origins", PF)]
 
@@ -81,6 +113,7 @@ _BUF_FIELDS = [
     ("terrain_levels", PI64), ("terrain_types", PI64), ("lstm_h", PF), ("lstm_c", PF),
     ("friction", PF), ("base_mass_delta", PF), ("extras_episode", PF), ("extras_terrain_level", PF),
     ("extras_time_outs", PU8), ("extras_episode_acc", PF), ("n_reset", PI32), ("n_fault", PI32), ("fault_total", PI64),
+    ("tg_state", PF), ("tg_traj", PF), ("trajectory", PF), ("prev_error", PF), ("push_timer", PF),
     ("inject_uniforms", PF), ("inject_levels", PI64)]
 
 
@@ -88,22 +121,24 @@ class lg_buffers(C.Structure):
     _fields_ = _BUF_FIELDS
 
 
-def buffer_shapes(N, A, B, O, F, H):
+def buffer_shapes(N, A, B, O, F, H, traj_N=0, traj_dN=1):
     """name -> (shape, numpy dtype string) of every lg_buffers entry."""
-    K = slot_noise(A) + O
+    K = (tslots(A)["noise"] if traj_N else slot_noise(A)) + O
     return {
+        "tg_state": ((N, TG_STRIDE), "f4"), "tg_traj": ((N, traj_N * traj_dN + 1, 2), "f4"),
+        "trajectory": ((N, max(traj_N, 1), 2), "f4"), "prev_error": ((N, 2), "f4"), "push_timer": ((N,), "f4"),
         "root_states": ((N, 13), "f4"), "dof_state": ((N, A, 2), "f4"), "contact_forces": ((N, B, 3), "f4"),
         "torques": ((N, A), "f4"), "actions": ((N, A), "f4"), "obs": ((N, O), "f4"), "rew": ((N,), "f4"),
         "reset": ((N,), "u1"), "time_out": ((N,), "u1"), "episode_length": ((N,), "i8"),
         "commands": ((N, 4), "f4"), "last_actions": ((N, A), "f4"), "last_dof_vel": ((N, A), "f4"),
         "last_root_vel": ((N, 6), "f4"), "feet_air_time": ((N, F), "f4"), "last_contacts": ((N, F), "u1"),
-        "episode_sums": ((NUM_REWARDS, N), "f4"), "base_lin_vel": ((N, 3), "f4"), "base_ang_vel": ((N, 3), "f4"),
+        "episode_sums": ((NUM_TERMS, N), "f4"), "base_lin_vel": ((N, 3), "f4"), "base_ang_vel": ((N, 3), "f4"),
         "projected_gravity": ((N, 3), "f4"), "measured_heights": ((N, max(H, 1)), "f4"),
         "env_origins": ((N, 3), "f4"), "terrain_levels": ((N,), "i8"), "terrain_types": ((N,), "i8"),
         "lstm_h": ((2, N * A, 8), "f4"), "lstm_c": ((2, N * A, 8), "f4"), "friction": ((N,), "f4"),
-        "base_mass_delta": ((N,), "f4"), "extras_episode": ((NUM_REWARDS,), "f4"),
+        "base_mass_delta": ((N,), "f4"), "extras_episode": ((NUM_TERMS,), "f4"),
         "extras_terrain_level": ((1,), "f4"), "extras_time_outs": ((N,), "u1"),
-        "extras_episode_acc": ((NUM_REWARDS + 2,), "f4"), "n_reset": ((1,), "i4"),
+        "extras_episode_acc": ((NUM_TERMS + 2,), "f4"), "n_reset": ((1,), "i4"),
         "n_fault": ((1,), "i4"), "fault_total": ((1,), "i8"),
         "inject_uniforms": ((N, K), "f4"), "inject_levels": ((N,), "i8")}
 

@@ -53,8 +53,9 @@ def load_actuator_weights(path_hint: str = "") -> np.ndarray:
 class EnvSetup:
     """Everything derived from (cfg, model) before any device work."""
 
-    def __init__(self, cfg, cm: dict, sim_dt: float, terrain=None, env_offset=0, total_envs=None, seed=1):
+    def __init__(self, cfg, cm: dict, sim_dt: float, terrain=None, env_offset=0, total_envs=None, seed=1, extra_terms=None):
         self.cfg, self.cm = cfg, cm
+        self.extra_terms = dict(extra_terms or {})          # name -> reward_terms._Term (declared by the env class)
         A, B = cm["num_dofs"], cm["num_bodies"]
         self.num_envs = N = cfg.env.num_envs
         self.num_dof = self.num_actions = A
@@ -68,14 +69,20 @@ class EnvSetup:
         self.dt = cfg.control.decimation * sim_dt
         self.obs_scales = cfg.normalization.obs_scales
         self.reward_scales = class_to_dict(cfg.rewards.scales)
-        self.command_ranges = class_to_dict(cfg.commands.ranges)
+        self.traj = self._parse_trajectory(cfg)             # None for the velocity-command env
+        if hasattr(cfg, "commands"):
+            self.command_ranges = class_to_dict(cfg.commands.ranges)
+        else:                                               # the trajectory env has no commands section
+            self.command_ranges = {k: [0.0, 0.0] for k in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")}
         self.push_time = math.ceil(cfg.domain_rand.push_interval_s / self.dt)
         self.max_push_vel = getattr(cfg.domain_rand, "max_push_vel", cfg.domain_rand.max_push_vel_xy)
+        if self.traj is not None:                            # a 6-vector there, and unused: pushes draw from max_push_vel_xy (:483-486)
+            self.max_push_vel = cfg.domain_rand.max_push_vel_xy
         if cfg.terrain.mesh_type not in ("heightfield", "trimesh"):
             cfg.terrain.curriculum = False
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = math.ceil(self.max_episode_length_s / self.dt)
-        use_curr = getattr(cfg.curriculum, "use_curriculum", False) if hasattr(cfg, "curriculum") else False
+        use_curr = getattr(getattr(cfg, "curriculum", None), "use_curriculum", False)
         if use_curr:
             raise NotImplementedError("command/push curriculum (cfg.curriculum.use_curriculum) is not supported")
 
@@ -142,19 +149,21 @@ class EnvSetup:
             self.height_points = np.zeros((0, 2), np.float32)
         self.num_height_points = H = self.height_points.shape[0]
         O = cfg.env.num_observations
-        if O != 12 + 3 * A + H:
-            raise ValueError(f"num_observations={O} does not match 12 + 3*{A} + {H} height points")
+        ncmd = 3 if self.traj is None else self.traj["N"] * 2        # commands[:3] | the N trajectory points (xy)
+        if O != 9 + ncmd + 3 * A + H:
+            raise ValueError(f"num_observations={O} does not match 9 + {ncmd} + 3*{A} + {H} height points")
 
-        # ---- noise scale vector
+        # ---- noise scale vector (legged_robot.py:507-530 / legged_robot_trajectory.py:563-587)
         ns, lvl, osc = cfg.noise.noise_scales, cfg.noise.noise_level, self.obs_scales
         nv = np.zeros(O, np.float32)
         nv[0:3] = ns.lin_vel * lvl * osc.lin_vel
         nv[3:6] = ns.ang_vel * lvl * osc.ang_vel
         nv[6:9] = ns.gravity * lvl
-        nv[12:12 + A] = ns.dof_pos * lvl * osc.dof_pos
-        nv[12 + A:12 + 2 * A] = ns.dof_vel * lvl * osc.dof_vel
+        j0 = 9 + ncmd
+        nv[j0:j0 + A] = ns.dof_pos * lvl * osc.dof_pos
+        nv[j0 + A:j0 + 2 * A] = ns.dof_vel * lvl * osc.dof_vel
         if self.measure_heights:
-            nv[12 + 3 * A:] = ns.height_measurements * lvl * osc.height_measurements
+            nv[j0 + 3 * A:] = ns.height_measurements * lvl * osc.height_measurements
         self.noise_scale_vec = nv
 
         # ---- reward scales: drop zeros, x dt, alphabetical order (class_to_dict walks dir())
@@ -163,9 +172,22 @@ class EnvSetup:
                 self.reward_scales.pop(k)
             else:
                 self.reward_scales[k] *= self.dt
-        unknown = [k for k in self.reward_scales if k not in capi.REWARD_NAMES]
+        unknown = [k for k in self.reward_scales if k not in capi.REWARD_NAMES and k not in self.extra_terms]
         if unknown:
-            raise AttributeError(f"no reward term named {unknown} (known: {capi.REWARD_NAMES})")
+            raise AttributeError(f"no reward term named {unknown}: builtin terms are {capi.REWARD_NAMES}; a subclass adds terms by "
+                                 "declaring them in extra_reward_terms() (envs/base/reward_terms.py), the counterpart of the "
+                                 "reference's _reward_<name> methods")
+        # active extra terms keep the index they are declared with; the sum runs over ALL active names alphabetically
+        # (class_to_dict walks dir(), helpers.py:111-126), termination excepted: it is applied last (legged_robot.py:199-206)
+        self.xterm_names = [k for k in self.extra_terms if k in self.reward_scales]
+        if len(self.xterm_names) > capi.MAX_XTERMS:
+            raise ValueError(f"at most {capi.MAX_XTERMS} extra reward terms")
+        if self.traj is not None and "stand_still" in self.reward_scales:
+            raise AttributeError("stand_still reads self.commands, which the trajectory env does not have "
+                                 "(legged_robot_trajectory.py:1088-1090 would raise as well)")
+        self.term_row = {k: (capi.REWARD_NAMES.index(k) if k in capi.REWARD_NAMES else capi.NUM_REWARDS + self.xterm_names.index(k))
+                         for k in self.reward_scales}
+        self.term_order = [self.term_row[k] for k in sorted(self.reward_scales) if k != "termination"]
 
         self.base_init_state = np.asarray(
             list(cfg.init_state.pos) + list(cfg.init_state.rot) + list(cfg.init_state.lin_vel)
@@ -178,6 +200,33 @@ class EnvSetup:
         self.seed = seed
 
     # ------------------------------------------------------------------------------
+    @staticmethod
+    def _parse_trajectory(cfg):
+        """cfg.rom / cfg.trajectory_generator of the trajectory-tracking env (legged_robot_trajectory.py:87-122), or None."""
+        if not hasattr(cfg, "trajectory_generator"):
+            return None
+        rom, tg, dr = cfg.rom, cfg.trajectory_generator, cfg.domain_rand
+        if rom.cls != "SingleInt2D":
+            raise NotImplementedError(f"reduced-order model {rom.cls!r}: the HIP step implements SingleInt2D (the fork's ANYmal "
+                                      "trajectory tasks); DoubleInt2D / unicycle models are not implemented")
+        if tg.cls != "TrajectoryGenerator" or tg.t_samp_cls != "UniformSampleHoldDT":
+            raise NotImplementedError(f"trajectory generator {tg.cls!r} / time sampler {tg.t_samp_cls!r} are not implemented")
+        if tg.weight_samp_cls != "UniformWeightSampler":
+            raise NotImplementedError(f"weight sampler {tg.weight_samp_cls!r}: only UniformWeightSampler is implemented")
+        dN = int(getattr(tg, "dN", 1))
+        if int(tg.N) * dN + 1 > capi.TRAJ_MAX_PTS:
+            raise ValueError("trajectory window longer than LG_TRAJ_MAX_PTS")
+        if dN != 1:
+            raise NotImplementedError("trajectory_generator.dN != 1 is not implemented")
+        return {"N": int(tg.N), "dN": dN, "rom_dt": float(rom.dt), "t_low": float(tg.t_low), "t_high": float(tg.t_high),
+                "freq_low": float(tg.freq_low), "freq_high": float(tg.freq_high), "prob_stationary": float(tg.prob_stationary),
+                "v_min": [float(v) for v in rom.v_min], "v_max": [float(v) for v in rom.v_max],
+                "obs_scale": [float(v) for v in cfg.normalization.obs_scales.trajectory],
+                "randomize_rom_distance": bool(getattr(dr, "randomize_rom_distance", False)),
+                "max_rom_dist": [float(v) for v in (getattr(dr, "max_rom_dist", None) or [0.0, 0.0])],
+                "zero_rom_dist_llh": float(getattr(dr, "zero_rom_distance_likelihood", 0.0)),
+                "max_push_vel_xy": float(dr.max_push_vel_xy), "push_t": [float(v) for v in dr.time_between_pushes]}
+
     def to_structs(self):
         """(lg_cfg, lg_model, keepalive list).  Pointers in lg_cfg reference numpy arrays that
         must stay alive until lg_create returns; they are in the keepalive list."""
@@ -214,9 +263,9 @@ class EnvSetup:
         c.decimation = cfg.control.decimation
         c.control_type = _CONTROL_TYPES[cfg.control.control_type]
         c.use_actuator_net = int(self.use_actuator_net)
-        c.heading_command = int(cfg.commands.heading_command)
+        c.heading_command = int(cfg.commands.heading_command) if hasattr(cfg, "commands") else 0
         c.max_episode_length = int(self.max_episode_length)
-        c.resample_steps = int(cfg.commands.resampling_time / self.dt)
+        c.resample_steps = int(cfg.commands.resampling_time / self.dt) if hasattr(cfg, "commands") else 1 << 30
         c.push_interval = int(self.push_time)
         c.push_robots = int(cfg.domain_rand.push_robots)
         c.add_noise = int(cfg.noise.add_noise)
@@ -256,11 +305,26 @@ class EnvSetup:
         c.obs_scale_lin_vel, c.obs_scale_ang_vel = osc.lin_vel, osc.ang_vel
         c.obs_scale_dof_pos, c.obs_scale_dof_vel, c.obs_scale_height = osc.dof_pos, osc.dof_vel, osc.height_measurements
         rw = cfg.rewards
-        c.tracking_sigma, c.soft_dof_vel_limit, c.soft_torque_limit = rw.tracking_sigma, rw.soft_dof_vel_limit, rw.soft_torque_limit
+        c.tracking_sigma = float(getattr(rw, "tracking_sigma", 0.25))
+        c.soft_dof_vel_limit, c.soft_torque_limit = rw.soft_dof_vel_limit, rw.soft_torque_limit
         c.base_height_target, c.max_contact_force = rw.base_height_target, rw.max_contact_force
         c.hf_hscale, c.hf_vscale, c.border_size = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale, cfg.terrain.border_size
         for k, name in enumerate(capi.REWARD_NAMES):
             c.rew_scale[k] = float(self.reward_scales.get(name, 0.0))
+        c.num_xterms = len(self.xterm_names)
+        for k, name in enumerate(self.xterm_names):
+            c.xterms[k] = self.extra_terms[name].to_struct(self.reward_scales[name])
+        c.num_terms = len(self.term_order)
+        _fill(c.term_order, self.term_order)
+        if self.traj is not None:
+            tj, t = self.traj, c.traj
+            t.enabled, t.N, t.dN, t.randomize_rom_distance = 1, tj["N"], tj["dN"], int(tj["randomize_rom_distance"])
+            for k in ("rom_dt", "t_low", "t_high", "freq_low", "freq_high", "prob_stationary", "zero_rom_dist_llh", "max_push_vel_xy"):
+                setattr(t, k, tj[k])
+            for k in ("v_min", "v_max", "obs_scale", "max_rom_dist"):
+                _fill(getattr(t, k), tj[k])
+            t.push_t_lo, t.push_t_hi = tj["push_t"]
+            c.feet_air_time_ungated = 1
         _fill(c.base_init_state, self.base_init_state.tolist())
         _fill(c.default_dof_pos, self.default_dof_pos.tolist())
         _fill(c.p_gains, self.p_gains.tolist())

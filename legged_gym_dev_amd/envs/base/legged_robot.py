@@ -79,8 +79,10 @@ class LeggedRobot(BaseTask):
         elif cfg.terrain.mesh_type not in (None, "plane", "none"):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [None, plane, heightfield, trimesh]")
         seed = getattr(cfg, "seed", 1)
+        self._reject_python_reward_methods()
         self.setup = EnvSetup(cfg, cm, sim_dt_float(sim_params.dt), terrain=self.terrain,
-                              env_offset=rank * self.num_envs, total_envs=total, seed=seed)
+                              env_offset=rank * self.num_envs, total_envs=total, seed=seed,
+                              extra_terms=self.extra_reward_terms())
         s = self.setup
         for name in ("dt", "obs_scales", "reward_scales", "command_ranges", "push_time", "max_push_vel",
                      "max_episode_length_s", "max_episode_length", "num_dof", "num_bodies", "dof_names", "body_names",
@@ -109,6 +111,18 @@ class LeggedRobot(BaseTask):
         self.extras = {}
         self.init_done = True
 
+    # ------------------------------------------------------------------ reward extension point
+    def extra_reward_terms(self):
+        """name -> term spec (envs/base/reward_terms.py): what a subclass of the reference adds as ``_reward_<name>`` methods
+        (legged_robot.py:605-629).  A term is active when ``cfg.rewards.scales.<name>`` is non-zero."""
+        return {}
+
+    def _reject_python_reward_methods(self):
+        own = [n for n in dir(type(self)) if n.startswith("_reward_")]
+        if own:
+            raise NotImplementedError(f"{type(self).__name__} defines {own}: reward terms run inside the HIP post-step kernel; declare "
+                                      "them in extra_reward_terms() (envs/base/reward_terms.py) instead of as tensor methods")
+
     # ------------------------------------------------------------------ tensor surface
     def _bind_views(self):
         t, dev = self.core.t, self.device
@@ -120,7 +134,9 @@ class LeggedRobot(BaseTask):
         self.obs_buf, self.rew_buf = t["obs"], t["rew"]
         self.reset_buf, self.time_out_buf = t["reset"].view(torch.bool), t["time_out"].view(torch.bool)
         self._episode_length_buf = t["episode_length"]
-        self.torques, self.actions, self.commands = t["torques"], t["actions"], t["commands"]
+        self.torques, self.actions = t["torques"], t["actions"]
+        if self.setup.traj is None:
+            self.commands = t["commands"]
         self.last_actions, self.last_dof_vel, self.last_root_vel = t["last_actions"], t["last_dof_vel"], t["last_root_vel"]
         self.feet_air_time, self.last_contacts = t["feet_air_time"], t["last_contacts"].view(torch.bool)
         self.base_lin_vel, self.base_ang_vel, self.projected_gravity = t["base_lin_vel"], t["base_ang_vel"], t["projected_gravity"]
@@ -135,8 +151,8 @@ class LeggedRobot(BaseTask):
         self.default_dof_pos = torch.tensor(s.default_dof_pos, device=dev).unsqueeze(0)
         self.p_gains, self.d_gains = torch.tensor(s.p_gains, device=dev), torch.tensor(s.d_gains, device=dev)
         self.noise_scale_vec = torch.tensor(s.noise_scale_vec, device=dev)
-        self.episode_sums = {k: t["episode_sums"][capi.REWARD_NAMES.index(k)] for k in s.reward_scales}
-        self._extras_episode = {"rew_" + k: t["extras_episode"][capi.REWARD_NAMES.index(k)] for k in s.reward_scales}
+        self.episode_sums = {k: t["episode_sums"][s.term_row[k]] for k in s.reward_scales}
+        self._extras_episode = {"rew_" + k: t["extras_episode"][s.term_row[k]] for k in s.reward_scales}
         if bool(self.cfg.terrain.curriculum):
             self._extras_episode["terrain_level"] = t["extras_terrain_level"][0]
         self._extras_time_outs = t["extras_time_outs"].view(torch.bool)

@@ -1,0 +1,61 @@
+"""Trajectory-tracking variant of the env (reference: legged_gym/envs/base/legged_robot_trajectory.py:51-1110, the class the
+fork's authors train): the velocity commands are replaced by a reference trajectory produced by a
+reduced-order model under a random input generator (trajopt/rom_dynamics.py:182-212,441-616), the observation carries the
+next N trajectory points relative to the robot, two reward terms track it (``tracking_rom`` :1060-1069,
+``differential_error`` :1100-1110) and pushes come from per-env timers (:150-160,486-492).
+
+All of it runs inside the same HIP step kernels as the base env (csrc/env_kernels.hip: lg_cfg.traj); this class only declares
+the two reward terms as data and exposes the extra buffers under the reference's attribute names.
+"""
+import torch
+
+from legged_gym_dev_amd import capi
+from .legged_robot import LeggedRobot
+from .reward_terms import ExpNegWeightedSqErr, SlopedErrChange
+
+
+class _TrajGenView:
+    """Read-only face of the device-side generator state under the reference's TrajectoryGenerator attribute names
+    (rom_dynamics.py:484-505)."""
+
+    def __init__(self, env):
+        self._t, self.N, self.dN = env.core.t, env.setup.traj["N"], env.setup.traj["dN"]
+        for name, (off, n) in capi.TG_FIELDS.items():
+            v = self._t["tg_state"][:, off:off + n]
+            setattr(self, {"const": "sample_hold_input", "extreme": "extreme_input", "stationary": "stationary_inds"}.get(name, name),
+                    v if n > 1 else v[:, 0])
+        self.trajectory = self._t["tg_traj"]
+
+    def get_trajectory(self):
+        return self._t["trajectory"]
+
+
+class LeggedRobotTrajectory(LeggedRobot):
+    def extra_reward_terms(self):
+        cfg = self.cfg
+        w = cfg.rewards.reward_weighting
+        weighting = [w.position, w.position]              # SingleInt2D.get_weighting_vector (rom_dynamics.py:209-211)
+        de = cfg.rewards.differential_error
+        return {"tracking_rom": ExpNegWeightedSqErr("root_pos", "traj0", weights=weighting, sigma=cfg.rewards.tracking_sigma),
+                "differential_error": SlopedErrChange("root_pos", "traj0", "prev_error", n=2, neg_slope=de.neg_slope,
+                                                      pos_slope=de.pos_slope)}
+
+    def _bind_views(self):
+        super()._bind_views()
+        t, tj = self.core.t, self.setup.traj
+        self.trajectory, self.prev_error = t["trajectory"], t["prev_error"]
+        self.time_until_next_push = t["push_timer"].view(self.num_envs, 1)
+        self.trajectory_scale = torch.tensor(tj["obs_scale"], device=self.device).repeat(tj["N"], 1)
+        self.traj_gen = _TrajGenView(self)
+        self.tracking_sigma = float(self.cfg.rewards.tracking_sigma)
+        self.max_rom_distance = torch.tensor(tj["max_rom_dist"], device=self.device)
+        self.zero_rom_dist_llh = tj["zero_rom_dist_llh"]
+        # construction-time draws of the reference: TrajectoryGenerator.ramp_v_end (rom_dynamics.py:494) and the push timers
+        # (legged_robot_trajectory.py:81-84), from torch's global generator like every other setup-time draw
+        vmin, vmax = torch.tensor(tj["v_min"]), torch.tensor(tj["v_max"])
+        total, lo = self.num_envs * self.world_size, self.rank * self.num_envs
+        ramp = (vmax - vmin) * torch.rand(total, 2) + vmin
+        timers = (tj["push_t"][1] - tj["push_t"][0]) * torch.rand(total, 1) + tj["push_t"][0]
+        off = capi.TG_FIELDS["ramp_v_end"][0]
+        t["tg_state"][:, off:off + 2].copy_(ramp[lo:lo + self.num_envs])
+        t["push_timer"].copy_(timers[lo:lo + self.num_envs, 0])

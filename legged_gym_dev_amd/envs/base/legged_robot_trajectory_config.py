@@ -1,0 +1,49 @@
+"""Configuration of the trajectory-tracking env variant (drop-in for the reference's LeggedRobotTrajectoryCfg /
+LeggedRobotTrajectoryCfgPPO, legged_gym/envs/base/legged_robot_trajectory_config.py:35-279).
+
+Values are the reference's.  As committed, that class cannot construct its env (the list with line numbers
+is in oracle/gen_fixtures_trajectory.py): the authors run it through hydra overrides (deep_tube_learning/configs/rl/
+default.yaml) that supply the missing fields.  They are real attributes here, with the values those overrides / the hopper
+trajectory config give them:
+    trajectory_generator.weight_samp_cls = 'UniformWeightSampler' (was the undefined 'WeightSamplerSampleAndHold'),
+    trajectory_generator.prob_stationary = 0.01, .dN = 1 (were rom.prob_stationary and .DN),
+    domain_rand.randomize_rom_distance = False, .max_rom_dist = [0, 0], .zero_rom_distance_likelihood = 0.25,
+    domain_rand.rigid_shape_properties.* = False, .randomize_inv_base_mass = False,
+    rewards.tracking_sigma = 0.25, curriculum.use_curriculum = False.
+"""
+from .base_config import BaseConfig, S, cfg_class
+from .legged_robot_config import LeggedRobotCfg, LeggedRobotCfgPPO
+
+_B = LeggedRobotCfg
+
+LeggedRobotTrajectoryCfg = cfg_class("LeggedRobotTrajectoryCfg", BaseConfig, dict(
+    env=S(num_envs=4096, num_observations=240, num_privileged_obs=None, num_actions=12, env_spacing=3.0, send_timeouts=True,
+          episode_length_s=20),
+    terrain=_B.terrain,
+    rom=S(cls='SingleInt2D', dt=0.1, vel_max=0.35, pos_max=1e9, z_min=[-1e9, -1e9], z_max=[1e9, 1e9], v_min=[-0.35, -0.35],
+          v_max=[0.35, 0.35], speed_curriculum=False, weight_curriculum=False, curriculum_threshold=0.05,
+          weights_curriculum_transition_rate=0.05, speed_curriculum_transition_rate=0.15, prob_stationary=0.0001,
+          stationary_duration=1.0),
+    trajectory_generator=S(cls='TrajectoryGenerator', t_samp_cls='UniformSampleHoldDT', weight_samp_cls='UniformWeightSampler',
+                           N=10, t_low=1, t_high=2, freq_low=0.01, freq_high=2, seed=42, DN=1, dN=1, prob_stationary=0.01),
+    init_state=_B.init_state,
+    control=_B.control,
+    asset=_B.asset,
+    domain_rand=S(randomize_friction=True, friction_range=[0.5, 1.25], randomize_base_mass=False, added_mass_range=[-1.0, 1.0],
+                  push_robots=True, push_interval_s=15, max_push_vel_xy=1.0, max_push_vel=[0.25, 0.25, 0.25, 0.75, 0.75, 0.75],
+                  time_between_pushes=[0.5, 10.0], randomize_rom_distance=False, max_rom_dist=[0.0, 0.0],
+                  zero_rom_distance_likelihood=0.25, randomize_inv_base_mass=False,
+                  rigid_shape_properties=S(randomize_restitution=False, randomize_compliance=False, randomize_thickness=False)),
+    rewards=S(scales=S(termination=-0.5), only_positive_rewards=False, soft_dof_pos_limit=1.0, soft_dof_vel_limit=1.0,
+              soft_torque_limit=1.0, base_height_target=1.0, max_contact_force=100.0, tracking_sigma=0.25,
+              differential_error=S(neg_slope=1.0, pos_slope=4.0),
+              reward_weighting=S(position=1.0, velocity=1.0, orientation=0.3, angular_velocity=0.2, v_perp=0.4)),
+    curriculum=S(use_curriculum=False, curriculum_steps=[2500, 5000]),
+    normalization=S(obs_scales=S(lin_vel=2.0, ang_vel=0.25, dof_pos=1.0, dof_vel=0.05, height_measurements=5.0, trajectory=[1.0, 1.0]),
+                    clip_observations=100.0, clip_actions=100.0),
+    noise=_B.noise,
+    viewer=_B.viewer,
+    sim=_B.sim,
+), doc=None, module=__name__)
+
+LeggedRobotTrajectoryCfgPPO = cfg_class("LeggedRobotTrajectoryCfgPPO", LeggedRobotCfgPPO, dict(), doc=None, module=__name__)

@@ -109,7 +109,8 @@ class HipEnvCore:
         bufs = capi.lg_buffers()
         self.lib.lg_get_buffers(self.ctx, C.byref(bufs))
         shapes = capi.buffer_shapes(setup.num_envs, setup.num_dof, setup.num_bodies, cfg.num_obs,
-                                    len(setup.feet_indices), setup.num_height_points)
+                                    len(setup.feet_indices), setup.num_height_points,
+                                    traj_N=setup.traj["N"] if setup.traj else 0, traj_dN=setup.traj["dN"] if setup.traj else 1)
         self.t = {}
         for name, (shape, dt) in shapes.items():
             ptr = C.cast(getattr(bufs, name), C.c_void_p).value

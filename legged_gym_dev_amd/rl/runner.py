@@ -14,7 +14,7 @@ from collections import deque
 
 import torch
 
-from legged_gym_dev_amd.capi import REWARD_NAMES as _REWARD_NAMES
+from legged_gym_dev_amd.capi import NUM_TERMS as _NUM_TERMS
 from .ppo import HipPPO
 
 
@@ -172,11 +172,12 @@ class OnPolicyRunner:
         self.env.core.t["extras_episode_acc"].zero_()
         nsteps = max(float(acc[-1]), 1.0)
         ep = {}
+        rows = self.env.setup.term_row
         for name in self.env.extras.get("episode", {}):
             if name == "terrain_level":
-                ep[name] = float(acc[-2]) / nsteps
-            elif name.startswith("rew_") and name[4:] in _REWARD_NAMES:
-                ep[name] = float(acc[_REWARD_NAMES.index(name[4:])]) / nsteps
+                ep[name] = float(acc[_NUM_TERMS]) / nsteps
+            elif name.startswith("rew_") and name[4:] in rows:
+                ep[name] = float(acc[rows[name[4:]]]) / nsteps
         faults = int(self.env.core.t["fault_total"].cpu())
         if self.rank != 0:
             return

@@ -17,9 +17,10 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
     e->model = *model;
     const int N = e->N = cfg->num_envs, A = e->A = cfg->num_actions, B = e->B = cfg->num_bodies;
     const int O = e->O = cfg->num_obs, F = e->F = cfg->num_feet, H = e->H = cfg->num_height_points;
-    e->K = LG_SLOT_NOISE(A) + O;
+    e->K = (cfg->traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A)) + O;
     if (A > LG_MAX_DOF || B > LG_MAX_BODIES || F > LG_MAX_FEET) { g_err = "model exceeds LG_MAX_*"; delete e; return -2; }
-    if (O != 12 + 3 * A + (cfg->measure_heights ? H : 0)) { g_err = "num_obs inconsistent with layout"; delete e; return -3; }
+    const int ocmd = cfg->traj.enabled ? 2 * cfg->traj.N : 3;
+    if (O != 9 + ocmd + 3 * A + (cfg->measure_heights ? H : 0)) { g_err = "num_obs inconsistent with layout"; delete e; return -3; }
     e->noise_vec.assign(cfg->noise_vec, cfg->noise_vec + O);
     if (H) e->height_points.assign(cfg->height_points, cfg->height_points + 2 * H);
     if (cfg->terrain_type == 1) {
@@ -35,11 +36,16 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
     z(e->torques, (size_t)N * A); z(e->actions, (size_t)N * A); z(e->obs, (size_t)N * O); z(e->rew, N);
     z(e->commands, (size_t)N * 4); z(e->last_actions, (size_t)N * A); z(e->last_dof_vel, (size_t)N * A);
     z(e->last_root_vel, (size_t)N * 6); z(e->feet_air_time, (size_t)N * F);
-    z(e->episode_sums, (size_t)LG_NUM_REWARDS * N); z(e->base_lin_vel, (size_t)N * 3);
+    z(e->episode_sums, (size_t)LG_NUM_TERMS * N); z(e->base_lin_vel, (size_t)N * 3);
     z(e->base_ang_vel, (size_t)N * 3); z(e->proj_grav, (size_t)N * 3); z(e->heights, (size_t)N * (H ? H : 1));
     z(e->env_origins, (size_t)N * 3); z(e->lstm_h, (size_t)2 * N * A * 8); z(e->lstm_c, (size_t)2 * N * A * 8);
-    z(e->friction, N); z(e->base_mass_delta, N); z(e->extras_episode, LG_NUM_REWARDS);
-    z(e->extras_terrain_level, 1); z(e->extras_episode_acc, LG_NUM_REWARDS + 2); z(e->inj_u, (size_t)N * e->K);
+    z(e->friction, N); z(e->base_mass_delta, N); z(e->extras_episode, LG_NUM_TERMS);
+    z(e->extras_terrain_level, 1); z(e->extras_episode_acc, LG_NUM_TERMS + 2);
+    {
+        const int npts = cfg->traj.enabled ? cfg->traj.N * cfg->traj.dN + 1 : 1, nobs = cfg->traj.enabled ? cfg->traj.N : 1;
+        z(e->tg_state, (size_t)N * LG_TG_STRIDE); z(e->tg_traj, (size_t)N * npts * 2); z(e->trajectory, (size_t)N * nobs * 2);
+        z(e->prev_error, (size_t)N * 2); z(e->push_timer, N);
+    } z(e->inj_u, (size_t)N * e->K);
     for (int i = 0; i < N; ++i) { e->root[(size_t)i * 13 + 6] = 1.0f; e->friction[i] = 1.0f; }
     e->reset.assign(N, 1); e->time_out.assign(N, 0); e->last_contacts.assign((size_t)N * F, 0);
     e->extras_time_outs.assign(N, 0); e->fault.assign(N, 0); e->ep_len.assign(N, 0); e->terrain_levels.assign(N, 0);
@@ -67,6 +73,8 @@ int lgo_get_buffers(void *ctx, lg_buffers *b) {
     b->extras_episode = e->extras_episode.data(); b->extras_terrain_level = e->extras_terrain_level.data();
     b->extras_time_outs = e->extras_time_outs.data(); b->n_reset = e->n_reset.data();
     b->extras_episode_acc = e->extras_episode_acc.data(); b->n_fault = e->n_fault.data(); b->fault_total = e->fault_total.data();
+    b->tg_state = e->tg_state.data(); b->tg_traj = e->tg_traj.data(); b->trajectory = e->trajectory.data();
+    b->prev_error = e->prev_error.data(); b->push_timer = e->push_timer.data();
     b->inject_uniforms = e->inj_u.data(); b->inject_levels = e->inj_levels.data();
     return 0;
 }

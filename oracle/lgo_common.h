@@ -46,7 +46,8 @@ struct Env {
     // state (host)
     std::vector<float> root, dof, contact, torques, actions, obs, rew, commands, last_actions, last_dof_vel,
         last_root_vel, feet_air_time, episode_sums, base_lin_vel, base_ang_vel, proj_grav, heights,
-        env_origins, lstm_h, lstm_c, friction, base_mass_delta, extras_episode, extras_terrain_level, extras_episode_acc, inj_u;
+        env_origins, lstm_h, lstm_c, friction, base_mass_delta, extras_episode, extras_terrain_level, extras_episode_acc, inj_u,
+        tg_state, tg_traj, trajectory, prev_error, push_timer;
     std::vector<uint8_t> reset, time_out, last_contacts, extras_time_outs, fault;
     std::vector<int64_t> ep_len, terrain_levels, terrain_types, inj_levels;
     std::vector<int32_t> n_reset, n_fault;
@@ -60,5 +61,10 @@ void simulate(Env &e);
 void post_physics_step(Env &e);
 void reset_all(Env &e);
 void reset_ids(Env &e, const int32_t *ids, int n);
+// trajectory env (lgo_traj.cpp)
+float uni(const Env &e, int env, int slot);
+void tg_callback_step(Env &e, int i);
+void tg_reset(Env &e, int i, const float z[2]);
+void tg_late_resample(Env &e, int i);
 
 }  // namespace lgo

@@ -31,10 +31,6 @@ static inline void quat_apply(const float q[4], const float b[3], float o[3]) {
 }
 static inline float clampf(float x, float lo, float hi) { return std::min(std::max(x, lo), hi); }
 
-static inline float uni(const Env &e, int env, int slot) {
-    if (e.inject) return e.inj_u[(size_t)env * e.K + slot];
-    return philox_uniform(e.cfg.seed, (uint32_t)(e.cfg.env_offset + env), (uint64_t)e.step_counter, (uint32_t)slot);
-}
 
 // LR:365-387
 static void resample_commands(Env &e, int i, int slot0) {
@@ -149,6 +145,7 @@ static float reward_term(Env &e, int i, int k, const RewardCtx &x) {
             s += (air[f] - 0.5f) * first;
             air[f] *= filt ? 0.0f : 1.0f;
         }
+        if (c.feet_air_time_ungated) return s;                        // LT:1071-1080: no command gate in the trajectory env
         float cn = std::sqrt(x.cmd[0] * x.cmd[0] + x.cmd[1] * x.cmd[1]);
         return s * (cn > 0.1f ? 1.0f : 0.0f);
     }
@@ -172,6 +169,53 @@ static float reward_term(Env &e, int i, int k, const RewardCtx &x) {
         int n = 0;
         for (int f = 0; f < F; ++f) n += x.cf[3 * c.feet_idx[f] + 2] > 0.1f ? 1 : 0;
         return n == 1 ? 1.0f : 0.0f;
+    }
+    }
+    return 0.0f;
+}
+
+// per-env signals an extra reward term may read (include/legged_hip.h lg_signal)
+static float signal_at(const Env &e, int i, int sig, int k, const RewardCtx &x) {
+    const lg_cfg &c = e.cfg;
+    switch (sig) {
+    case LG_SIG_BASE_LIN_VEL: return x.blv[k];
+    case LG_SIG_BASE_ANG_VEL: return x.bav[k];
+    case LG_SIG_PROJ_GRAVITY: return x.pg[k];
+    case LG_SIG_COMMANDS: return x.cmd[k];
+    case LG_SIG_ROOT_POS: return e.root[(size_t)i * 13 + k];
+    case LG_SIG_TRAJ0: return e.trajectory[(size_t)i * (c.traj.enabled ? c.traj.N : 1) * 2 + k];
+    case LG_SIG_PREV_ERROR: return e.prev_error[(size_t)i * 2 + k];
+    case LG_SIG_DOF_POS_REL: return x.q[k] - c.default_dof_pos[k];
+    case LG_SIG_DOF_VEL: return x.qd[k];
+    case LG_SIG_TORQUES: return x.tau[k];
+    case LG_SIG_ACTIONS: return x.act[k];
+    case LG_SIG_LAST_ACTIONS: return x.lact[k];
+    }
+    return 0.0f;
+}
+// generic extra terms (legged_hip.h lg_xterm_kind); tracking_rom = LT:1060-1069, differential_error = LT:1100-1110
+static float xterm_value(const Env &e, int i, const lg_xterm &t, const RewardCtx &x) {
+    float s = 0.0f;
+    switch (t.kind) {
+    case LG_XT_EXP_NEG_WSQ_ERR:
+        for (int k = 0; k < t.n; ++k) {
+            const float d = signal_at(e, i, t.sig_a, t.off_a + k, x) - signal_at(e, i, t.sig_b, t.off_b + k, x);
+            s += d * d * t.w[k];
+        }
+        return std::exp(-s / t.p[0]);
+    case LG_XT_WSQ:
+        for (int k = 0; k < t.n; ++k) { const float a = signal_at(e, i, t.sig_a, t.off_a + k, x); s += t.w[k] * a * a; }
+        return s;
+    case LG_XT_SLOPED_ERR_CHANGE: {
+        float pn = 0.0f;
+        for (int k = 0; k < t.n; ++k) {
+            const float d = signal_at(e, i, t.sig_a, t.off_a + k, x) - signal_at(e, i, t.sig_b, t.off_b + k, x);
+            const float te = d * d, pc = signal_at(e, i, t.sig_c, t.off_c + k, x);
+            s += te * te;
+            pn += pc * pc;
+        }
+        const float diff = std::sqrt(s) - std::sqrt(pn);
+        return (diff < 0.0f ? t.p[0] : t.p[1]) * diff;
     }
     }
     return 0.0f;
@@ -201,17 +245,31 @@ static void reset_env(Env &e, int i) {
         const float *to = &e.terrain_origins[((size_t)lvl * c.terrain_num_cols + e.terrain_types[i]) * 3];
         org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
     }
+    const bool tj = c.traj.enabled;
+    const int s_dof = tj ? LG_TSLOT_DOF : LG_SLOT_DOF, s_xy = tj ? LG_TSLOT_XY(A) : LG_SLOT_XY(A), s_vel = tj ? LG_TSLOT_VEL(A) : LG_SLOT_VEL(A);
     for (int j = 0; j < A; ++j) {                                    // LR:415-430
-        float u = uni(e, i, LG_SLOT_DOF + j);
+        float u = uni(e, i, s_dof + j);
         e.dof[((size_t)i * A + j) * 2] = c.default_dof_pos[j] * ((1.5f - 0.5f) * u + 0.5f);
         e.dof[((size_t)i * A + j) * 2 + 1] = 0.0f;
     }
     for (int k = 0; k < 13; ++k) r[k] = c.base_init_state[k];       // LR:432-454
     for (int k = 0; k < 3; ++k) r[k] += org[k];
     if (c.custom_origins)
-        for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(e, i, LG_SLOT_XY(A) + k) + (-1.0f);
-    for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(e, i, LG_SLOT_VEL(A) + k) + (-0.5f);
-    resample_commands(e, i, LG_SLOT_RCMD(A));
+        for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(e, i, s_xy + k) + (-1.0f);
+    for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(e, i, s_vel + k) + (-0.5f);
+    if (tj) {                                                        // LT:186 reset_traj :222-229 instead of a command resample
+        float z[2] = {r[0], r[1]};
+        if (c.traj.randomize_rom_distance && uni(e, i, LG_TSLOT_ROMD(A)) > c.traj.zero_rom_dist_llh)
+            for (int k = 0; k < 2; ++k)
+                z[k] += (c.traj.max_rom_dist[k] - (-c.traj.max_rom_dist[k])) * uni(e, i, LG_TSLOT_ROMD(A) + 1 + k) + (-c.traj.max_rom_dist[k]);
+        tg_reset(e, i, z);
+        for (int k = 0; k < 2; ++k) {                                // LT:199: against the trajectory the callback computed (not refreshed)
+            const float d = e.trajectory[(size_t)i * c.traj.N * 2 + k] - r[k];
+            e.prev_error[(size_t)i * 2 + k] = d * d;
+        }
+    } else {
+        resample_commands(e, i, LG_SLOT_RCMD(A));
+    }
     for (int j = 0; j < A; ++j) { e.last_actions[(size_t)i * A + j] = 0.0f; e.last_dof_vel[(size_t)i * A + j] = 0.0f; }
     for (int f = 0; f < e.F; ++f) e.feet_air_time[(size_t)i * e.F + f] = 0.0f;
     e.ep_len[i] = 0;
@@ -244,9 +302,10 @@ void post_physics_step(Env &e) {
         quat_rotate_inverse(r + 3, r + 7, blv);                       // LR:118-121
         quat_rotate_inverse(r + 3, r + 10, bav);
         quat_rotate_inverse(r + 3, gvec, pg);
-        // ---- _post_physics_step_callback LR:343-363
-        if (e.ep_len[i] % c.resample_steps == 0) resample_commands(e, i, LG_SLOT_CMD);
-        if (c.heading_command) {
+        // ---- _post_physics_step_callback LR:343-363 / LT:405-417
+        if (c.traj.enabled) tg_callback_step(e, i);
+        else if (e.ep_len[i] % c.resample_steps == 0) resample_commands(e, i, LG_SLOT_CMD);
+        if (c.heading_command && !c.traj.enabled) {
             const float fwd0[3] = {1.0f, 0.0f, 0.0f};
             float fwd[3];
             quat_apply(r + 3, fwd0, fwd);
@@ -259,7 +318,15 @@ void post_physics_step(Env &e) {
             cmd[2] = clampf(0.5f * ang, -1.0f, 1.0f);
         }
         if (c.measure_heights) get_heights(e, i);
-        if (push_now) {                                               // LR:456-461
+        if (c.traj.enabled) {                                         // LT:150-160: per-env push timers (pushes are unconditional there)
+            e.push_timer[i] -= c.dt;
+            if (e.push_timer[i] <= 0.0f) {
+                const float mv = c.traj.max_push_vel_xy;                  // LT:483-486
+                r[7] = (mv - (-mv)) * uni(e, i, LG_TSLOT_PUSH) + (-mv);
+                r[8] = (mv - (-mv)) * uni(e, i, LG_TSLOT_PUSH + 1) + (-mv);
+                e.push_timer[i] = (c.traj.push_t_hi - c.traj.push_t_lo) * uni(e, i, LG_TSLOT_TIMER) + c.traj.push_t_lo;
+            }
+        } else if (push_now) {                                        // LR:456-461
             r[7] = (c.max_push_vel - (-c.max_push_vel)) * uni(e, i, LG_SLOT_PUSH) + (-c.max_push_vel);
             r[8] = (c.max_push_vel - (-c.max_push_vel)) * uni(e, i, LG_SLOT_PUSH + 1) + (-c.max_push_vel);
         }
@@ -278,9 +345,11 @@ void post_physics_step(Env &e) {
         x.q = q; x.qd = qd; x.tau = &e.torques[(size_t)i * A]; x.act = &e.actions[(size_t)i * A];
         x.lact = &e.last_actions[(size_t)i * A]; x.lqd = &e.last_dof_vel[(size_t)i * A];
         float rew = 0.0f;
-        for (int k = 0; k < LG_NUM_REWARDS; ++k) {
-            if (k == LG_REW_TERMINATION || c.rew_scale[k] == 0.0f) continue;
-            float v = reward_term(e, i, k, x) * c.rew_scale[k];
+        for (int o = 0; o < c.num_terms; ++o) {                       // alphabetical over builtin and extra terms (LR:605-629)
+            const int k = c.term_order[o];
+            float v;
+            if (k < LG_NUM_REWARDS) v = reward_term(e, i, k, x) * c.rew_scale[k];
+            else v = xterm_value(e, i, c.xterms[k - LG_NUM_REWARDS], x) * c.xterms[k - LG_NUM_REWARDS].scale;
             rew += v;
             e.episode_sums[(size_t)k * N + i] += v;
         }
@@ -302,8 +371,9 @@ void post_physics_step(Env &e) {
     e.n_fault[0] = n_fault;
     e.fault_total[0] += n_fault;
     if (n_reset > 0) {
-        for (int k = 0; k < LG_NUM_REWARDS; ++k) {
-            if (c.rew_scale[k] == 0.0f) { e.extras_episode[k] = 0.0f; continue; }
+        for (int k = 0; k < LG_NUM_TERMS; ++k) {
+            const float sc = k < LG_NUM_REWARDS ? c.rew_scale[k] : (k - LG_NUM_REWARDS < c.num_xterms ? c.xterms[k - LG_NUM_REWARDS].scale : 0.0f);
+            if (sc == 0.0f) { e.extras_episode[k] = 0.0f; continue; }
             float s = 0.0f;
             for (int i = 0; i < N; ++i)
                 if (was_reset[i]) { s += e.episode_sums[(size_t)k * N + i]; e.episode_sums[(size_t)k * N + i] = 0.0f; }
@@ -318,10 +388,13 @@ void post_physics_step(Env &e) {
             e.extras_terrain_level[0] = s / (float)N;
         }
         if (c.send_timeouts) std::memcpy(e.extras_time_outs.data(), e.time_out.data(), N);
+        if (c.traj.enabled)                                           // the reset loop's get_input_t reaches every env (lgo_traj.cpp)
+            for (int i = 0; i < N; ++i)
+                if (!was_reset[i]) tg_late_resample(e, i);
     }
-    for (int k = 0; k < LG_NUM_REWARDS; ++k) e.extras_episode_acc[k] += e.extras_episode[k];   // rsl_rl log(): mean over the steps
-    e.extras_episode_acc[LG_NUM_REWARDS] += e.extras_terrain_level[0];
-    e.extras_episode_acc[LG_NUM_REWARDS + 1] += 1.0f;
+    for (int k = 0; k < LG_NUM_TERMS; ++k) e.extras_episode_acc[k] += e.extras_episode[k];   // rsl_rl log(): mean over the steps
+    e.extras_episode_acc[LG_NUM_TERMS] += e.extras_terrain_level[0];
+    e.extras_episode_acc[LG_NUM_TERMS + 1] += 1.0f;
     // ---- compute_observations LR:208-226, clip LR:100-103, bookkeeping LR:132-134
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
@@ -333,21 +406,29 @@ void post_physics_step(Env &e) {
             o[3 + k] = e.base_ang_vel[3 * i + k] * c.obs_scale_ang_vel;
             o[6 + k] = e.proj_grav[3 * i + k];
         }
-        o[9] = cmd[0] * c.obs_scale_lin_vel;
-        o[10] = cmd[1] * c.obs_scale_lin_vel;
-        o[11] = cmd[2] * c.obs_scale_ang_vel;
+        int ob = 12;                                                  // first joint entry
+        if (c.traj.enabled) {                                         // LT:280-288: trajectory relative to the robot, scaled per dim
+            ob = 9 + 2 * c.traj.N;
+            for (int p = 0; p < c.traj.N; ++p)
+                for (int d = 0; d < 2; ++d)
+                    o[9 + 2 * p + d] = (e.trajectory[((size_t)i * c.traj.N + p) * 2 + d] - r[d]) * c.traj.obs_scale[d];
+        } else {
+            o[9] = cmd[0] * c.obs_scale_lin_vel;
+            o[10] = cmd[1] * c.obs_scale_lin_vel;
+            o[11] = cmd[2] * c.obs_scale_ang_vel;
+        }
         for (int j = 0; j < A; ++j) {
             float q = e.dof[((size_t)i * A + j) * 2], qd = e.dof[((size_t)i * A + j) * 2 + 1];
-            o[12 + j] = (q - c.default_dof_pos[j]) * c.obs_scale_dof_pos;
-            o[12 + A + j] = qd * c.obs_scale_dof_vel;
-            o[12 + 2 * A + j] = e.actions[(size_t)i * A + j];
+            o[ob + j] = (q - c.default_dof_pos[j]) * c.obs_scale_dof_pos;
+            o[ob + A + j] = qd * c.obs_scale_dof_vel;
+            o[ob + 2 * A + j] = e.actions[(size_t)i * A + j];
         }
         if (c.measure_heights)
             for (int h = 0; h < e.H; ++h)
-                o[12 + 3 * A + h] = clampf(r[2] - 0.5f - e.heights[(size_t)i * e.H + h], -1.0f, 1.0f) * c.obs_scale_height;
+                o[ob + 3 * A + h] = clampf(r[2] - 0.5f - e.heights[(size_t)i * e.H + h], -1.0f, 1.0f) * c.obs_scale_height;
         for (int k = 0; k < O; ++k) {
             float v = o[k];
-            if (c.add_noise) v += (2.0f * uni(e, i, LG_SLOT_NOISE(A) + k) - 1.0f) * e.noise_vec[k];
+            if (c.add_noise) v += (2.0f * uni(e, i, (c.traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A)) + k) - 1.0f) * e.noise_vec[k];
             o[k] = clampf(v, -c.clip_obs, c.clip_obs);
         }
         for (int j = 0; j < A; ++j) {
@@ -361,7 +442,7 @@ void post_physics_step(Env &e) {
 // base_task.py:113 reset_idx(arange(N)) -- no extras bookkeeping needed by callers
 void reset_all(Env &e) {
     for (int i = 0; i < e.N; ++i) {
-        for (int k = 0; k < LG_NUM_REWARDS; ++k) e.episode_sums[(size_t)k * e.N + i] = 0.0f;
+        for (int k = 0; k < LG_NUM_TERMS; ++k) e.episode_sums[(size_t)k * e.N + i] = 0.0f;
         reset_env(e, i);
     }
 }
@@ -370,8 +451,9 @@ void reset_all(Env &e) {
 void reset_ids(Env &e, const int32_t *ids, int n) {
     const lg_cfg &c = e.cfg;
     if (n == 0) return;                                               // LR:156-157
-    for (int k = 0; k < LG_NUM_REWARDS; ++k) {
-        if (c.rew_scale[k] == 0.0f) { e.extras_episode[k] = 0.0f; continue; }
+    for (int k = 0; k < LG_NUM_TERMS; ++k) {
+        const float sc = k < LG_NUM_REWARDS ? c.rew_scale[k] : (k - LG_NUM_REWARDS < c.num_xterms ? c.xterms[k - LG_NUM_REWARDS].scale : 0.0f);
+        if (sc == 0.0f) { e.extras_episode[k] = 0.0f; continue; }
         float s = 0.0f;
         for (int q = 0; q < n; ++q) { s += e.episode_sums[(size_t)k * e.N + ids[q]]; e.episode_sums[(size_t)k * e.N + ids[q]] = 0.0f; }
         e.extras_episode[k] = (s / (float)n) / c.episode_length_s;

@@ -17,7 +17,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_DIR, f) for f in ("lgo_env.cpp", "lgo_physics.cpp", "lgo_api.cpp", "lgo_common.h")]
+    srcs = [os.path.join(_DIR, f) for f in ("lgo_env.cpp", "lgo_traj.cpp", "lgo_physics.cpp", "lgo_api.cpp", "lgo_common.h")]
     srcs.append(os.path.join(os.path.dirname(_DIR), "include", "legged_hip.h"))
     if (not force and os.path.isfile(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs if os.path.isfile(s))):
@@ -55,7 +55,8 @@ class OracleEnv:
         bufs = capi.lg_buffers()
         self.lib.lgo_get_buffers(self.ctx, C.byref(bufs))
         shapes = capi.buffer_shapes(setup.num_envs, setup.num_dof, setup.num_bodies, cfg.num_obs,
-                                    len(setup.feet_indices), setup.num_height_points)
+                                    len(setup.feet_indices), setup.num_height_points,
+                                    traj_N=setup.traj["N"] if setup.traj else 0, traj_dN=setup.traj["dN"] if setup.traj else 1)
         self.buf = {}
         for name, (shape, dt) in shapes.items():
             ptr = getattr(bufs, name)

@@ -58,3 +58,28 @@ def test_actuator_lstm_golden(oracle_built):
             np.testing.assert_allclose(env.get("lstm_c"), g[f"c{k + 1}"], rtol=1e-4, atol=1e-5)
     finally:
         env.close()
+
+
+TRAJ = "anymal_c_flat_trajectory"
+
+
+def test_trajectory_setup_matches_reference_constants():
+    """Host setup of the trajectory-tracking variant against what the reference's LeggedRobotTrajectory
+    derived: index sets, gains, noise vector (trajectory block unscaled), reward order incl. the two extra terms, ROM bounds,
+    generator parameters, slot layout."""
+    z, meta = harness.load_fixture(TRAJ)
+    setup, _ = harness.make_setup(TRAJ, z, meta)
+    harness.check_setup_against_fixture(setup, z, meta)
+    assert setup.xterm_names == ["tracking_rom", "differential_error"]
+
+
+def test_oracle_replays_reference_trajectory_steps(oracle_built):
+    """The oracle's trajectory env (lgo_traj.cpp + the traj branches of lgo_env.cpp) against six steps of the reference's own
+    LeggedRobotTrajectory / AnymalTrajectory / TrajectoryGenerator: this is what pins it."""
+    z, meta = harness.load_fixture(TRAJ)
+    setup, _ = harness.make_setup(TRAJ, z, meta)
+    env = oracle_built.OracleEnv(setup)
+    try:
+        harness.replay_trajectory_fixture(env, z, meta)
+    finally:
+        env.close()
