@@ -66,7 +66,20 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
         g_err = "no physics kernel instantiated for this topology (have 4x3 and 2x6)";
         return -4;
     }
-    if (O != 12 + 3 * A + (cfg->measure_heights ? H : 0)) { g_err = "num_obs inconsistent with the observation layout"; return -5; }
+    const int ncmd = cfg->traj.enabled ? 2 * cfg->traj.N : 3;
+    if (O != 9 + ncmd + 3 * A + (cfg->measure_heights ? H : 0)) { g_err = "num_obs inconsistent with the observation layout"; return -5; }
+    if (cfg->traj.enabled && (cfg->traj.N < 1 || cfg->traj.dN != 1 || cfg->traj.N * cfg->traj.dN + 1 > LG_TRAJ_MAX_PTS)) {
+        g_err = "trajectory window outside 1..LG_TRAJ_MAX_PTS-1 points (dN must be 1)"; return -5;
+    }
+    if (cfg->num_xterms < 0 || cfg->num_xterms > LG_MAX_XTERMS || cfg->num_terms < 0 || cfg->num_terms > LG_NUM_TERMS) {
+        g_err = "bad reward term table"; return -5;
+    }
+    for (int k = 0; k < cfg->num_terms; ++k)
+        if (cfg->term_order[k] < 0 || cfg->term_order[k] >= LG_NUM_REWARDS + cfg->num_xterms) { g_err = "term_order entry out of range"; return -5; }
+    for (int k = 0; k < cfg->num_xterms; ++k)
+        if (cfg->xterms[k].n < 0 || cfg->xterms[k].n > 8 || cfg->xterms[k].kind < 0 || cfg->xterms[k].kind > LG_XT_SLOPED_ERR_CHANGE) {
+            g_err = "bad extra reward term"; return -5;
+        }
     if (cfg->terrain_type == 1 && !height_samples) { g_err = "terrain_type=1 needs height samples"; return -6; }
     if (!cfg->noise_vec) { g_err = "cfg.noise_vec is null"; return -7; }
 
@@ -77,7 +90,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     h.cfg = *cfg;
     h.model = *model;
     h.cfg.noise_vec = h.cfg.height_points = h.cfg.terrain_origins = nullptr;
-    h.K = LG_SLOT_NOISE(A) + O;
+    h.K = (cfg->traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A)) + O;
 
     // sphere slots per leg (same link pattern on every leg) + base spheres one per lane
     {
@@ -137,15 +150,20 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     DA(b.reset, N); DA(b.time_out, N); DA(b.episode_length, N);
     DA(b.commands, (size_t)N * 4); DA(b.last_actions, (size_t)N * A); DA(b.last_dof_vel, (size_t)N * A);
     DA(b.last_root_vel, (size_t)N * 6); DA(b.feet_air_time, (size_t)N * F); DA(b.last_contacts, (size_t)N * F);
-    DA(b.episode_sums, (size_t)LG_NUM_REWARDS * N); DA(b.base_lin_vel, (size_t)N * 3); DA(b.base_ang_vel, (size_t)N * 3);
+    DA(b.episode_sums, (size_t)LG_NUM_TERMS * N); DA(b.base_lin_vel, (size_t)N * 3); DA(b.base_ang_vel, (size_t)N * 3);
     DA(b.projected_gravity, (size_t)N * 3); DA(b.measured_heights, (size_t)N * (H ? H : 1));
     DA(b.env_origins, (size_t)N * 3); DA(b.terrain_levels, N); DA(b.terrain_types, N);
     DA(b.lstm_h, (size_t)2 * N * A * 8); DA(b.lstm_c, (size_t)2 * N * A * 8);
     DA(b.friction, N); DA(b.base_mass_delta, N);
-    DA(b.extras_episode, LG_NUM_REWARDS); DA(b.extras_terrain_level, 1); DA(b.extras_time_outs, N); DA(b.n_reset, 1);
-    DA(b.n_fault, 1); DA(b.fault_total, 1); DA(h.fault_count, 1); DA(b.extras_episode_acc, LG_NUM_REWARDS + 2);
+    DA(b.extras_episode, LG_NUM_TERMS); DA(b.extras_terrain_level, 1); DA(b.extras_time_outs, N); DA(b.n_reset, 1);
+    DA(b.n_fault, 1); DA(b.fault_total, 1); DA(h.fault_count, 1); DA(b.extras_episode_acc, LG_NUM_TERMS + 2);
+    {
+        const int npts = cfg->traj.enabled ? cfg->traj.N * cfg->traj.dN + 1 : 1, nobs = cfg->traj.enabled ? cfg->traj.N : 1;
+        DA(b.tg_state, (size_t)N * LG_TG_STRIDE); DA(b.tg_traj, (size_t)N * npts * 2); DA(b.trajectory, (size_t)N * nobs * 2);
+        DA(b.prev_error, (size_t)N * 2); DA(b.push_timer, N); DA(h.reset_mark, N);
+    }
     DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N);
-    DA(h.ep_accum, LG_NUM_REWARDS); DA(h.reset_count, 1); DA(h.fault, N);
+    DA(h.ep_accum, LG_NUM_TERMS); DA(h.reset_count, 1); DA(h.fault, N);
     {   // defaults: identity quaternion, unit friction, reset flags = 1 (base_task.py:72)
         float *tmp = new float[(size_t)N * 13]();
         for (int i = 0; i < N; ++i) tmp[(size_t)i * 13 + 6] = 1.0f;

@@ -3,6 +3,7 @@
 // (envs/anymal_c/anymal.py:71-81, "AN"), Cassie._reward_no_fly (envs/cassie/cassie.py:43-46, "CA").
 #include "lg_device.h"
 #include "lg_physics.h"
+#include "lg_traj.h"
 
 // ------------------------------------------------------------------------------------------------
 // LR:86-87  actions = clip(actions, +-clip_actions)
@@ -314,6 +315,7 @@ __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &
             s += (a - 0.5f) * first;
             air[f] = filt ? 0.0f : a;
         }
+        if (c.feet_air_time_ungated) return s;                        // trajectory env: no command gate (LT:1071-1080)
         float cn = sqrtf(x.cmd[0] * x.cmd[0] + x.cmd[1] * x.cmd[1]);
         return s * (cn > 0.1f ? 1.0f : 0.0f);
     }
@@ -342,6 +344,74 @@ __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &
     return 0.0f;
 }
 
+// per-env signals an extra reward term may read (legged_hip.h lg_signal)
+__device__ float signal_at(const DevParams *P, int i, int sig, int k, const RewardCtx &x) {
+    const lg_cfg &c = P->cfg;
+    switch (sig) {
+    case LG_SIG_BASE_LIN_VEL: return k == 0 ? x.blv.x : k == 1 ? x.blv.y : x.blv.z;
+    case LG_SIG_BASE_ANG_VEL: return k == 0 ? x.bav.x : k == 1 ? x.bav.y : x.bav.z;
+    case LG_SIG_PROJ_GRAVITY: return k == 0 ? x.pg.x : k == 1 ? x.pg.y : x.pg.z;
+    case LG_SIG_COMMANDS: return x.cmd[k];
+    case LG_SIG_ROOT_POS: return P->buf.root_states[(size_t)i * 13 + k];
+    case LG_SIG_TRAJ0: return P->buf.trajectory[(size_t)i * (c.traj.enabled ? c.traj.N : 1) * 2 + k];
+    case LG_SIG_PREV_ERROR: return P->buf.prev_error[(size_t)i * 2 + k];
+    case LG_SIG_DOF_POS_REL: return x.dof[2 * k] - c.default_dof_pos[k];
+    case LG_SIG_DOF_VEL: return x.dof[2 * k + 1];
+    case LG_SIG_TORQUES: return x.tau[k];
+    case LG_SIG_ACTIONS: return x.act[k];
+    case LG_SIG_LAST_ACTIONS: return x.lact[k];
+    }
+    return 0.0f;
+}
+// generic extra terms (legged_hip.h lg_xterm_kind): what a subclass of the reference writes as a _reward_<name> method
+// (LR:605-629); tracking_rom LT:1060-1069 and differential_error LT:1100-1110 are declared through it
+__device__ float xterm_value(const DevParams *P, int i, const lg_xterm &t, const RewardCtx &x) {
+    float s = 0.0f;
+    switch (t.kind) {
+    case LG_XT_EXP_NEG_WSQ_ERR:
+        for (int k = 0; k < t.n; ++k) {
+            const float d = signal_at(P, i, t.sig_a, t.off_a + k, x) - signal_at(P, i, t.sig_b, t.off_b + k, x);
+            s += d * d * t.w[k];
+        }
+        return expf(-s / t.p[0]);
+    case LG_XT_WSQ:
+        for (int k = 0; k < t.n; ++k) { const float a = signal_at(P, i, t.sig_a, t.off_a + k, x); s += t.w[k] * a * a; }
+        return s;
+    case LG_XT_SLOPED_ERR_CHANGE: {
+        float pn = 0.0f;
+        for (int k = 0; k < t.n; ++k) {
+            const float d = signal_at(P, i, t.sig_a, t.off_a + k, x) - signal_at(P, i, t.sig_b, t.off_b + k, x);
+            const float te = d * d, pc = signal_at(P, i, t.sig_c, t.off_c + k, x);
+            s += te * te;
+            pn += pc * pc;
+        }
+        const float diff = sqrtf(s) - sqrtf(pn);
+        return (diff < 0.0f ? t.p[0] : t.p[1]) * diff;
+    }
+    }
+    return 0.0f;
+}
+__device__ __forceinline__ float term_scale(const lg_cfg &c, int k) {
+    return k < LG_NUM_REWARDS ? c.rew_scale[k] : (k - LG_NUM_REWARDS < c.num_xterms ? c.xterms[k - LG_NUM_REWARDS].scale : 0.0f);
+}
+
+// reset_traj (LT:222-229) + the stale-trajectory error of LT:199 for one env; root already holds the post-reset pose
+__device__ void reset_trajectory(const DevParams *P, int i, int64_t counter, int inject) {
+    const lg_cfg &c = P->cfg;
+    const int A = c.num_actions;
+    const float *r = P->buf.root_states + (size_t)i * 13;
+    float zx = r[0], zy = r[1];
+    if (c.traj.randomize_rom_distance && uni(P, i, LG_TSLOT_ROMD(A), counter, inject) > c.traj.zero_rom_dist_llh) {
+        zx += (c.traj.max_rom_dist[0] - (-c.traj.max_rom_dist[0])) * uni(P, i, LG_TSLOT_ROMD(A) + 1, counter, inject) + (-c.traj.max_rom_dist[0]);
+        zy += (c.traj.max_rom_dist[1] - (-c.traj.max_rom_dist[1])) * uni(P, i, LG_TSLOT_ROMD(A) + 2, counter, inject) + (-c.traj.max_rom_dist[1]);
+    }
+    tg_reset(P, i, zx, zy, counter, inject);
+    for (int k = 0; k < 2; ++k) {
+        const float d = P->buf.trajectory[(size_t)i * c.traj.N * 2 + k] - r[k];
+        P->buf.prev_error[(size_t)i * 2 + k] = d * d;
+    }
+}
+
 // LR:147-187 (+:415-454, :463-486, AN:56-60) for one env
 __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
     const lg_cfg &c = P->cfg;
@@ -367,21 +437,25 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
         const float *to = P->terrain_origins + ((size_t)lvl * c.terrain_num_cols + P->buf.terrain_types[i]) * 3;
         org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
     }
+    const bool tj = c.traj.enabled;
+    const int s_dof = tj ? LG_TSLOT_DOF : LG_SLOT_DOF, s_xy = tj ? LG_TSLOT_XY(A) : LG_SLOT_XY(A), s_vel = tj ? LG_TSLOT_VEL(A) : LG_SLOT_VEL(A);
     float2 *dof = reinterpret_cast<float2 *>(P->buf.dof_state) + (size_t)i * A;
     for (int j = 0; j < A; ++j) {
-        float u = uni(P, i, LG_SLOT_DOF + j, counter, inject);
+        float u = uni(P, i, s_dof + j, counter, inject);
         dof[j] = make_float2(c.default_dof_pos[j] * ((1.5f - 0.5f) * u + 0.5f), 0.0f);
     }
     for (int k = 0; k < 13; ++k) r[k] = c.base_init_state[k];
     for (int k = 0; k < 3; ++k) r[k] += org[k];
     if (c.custom_origins)
-        for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(P, i, LG_SLOT_XY(A) + k, counter, inject) + (-1.0f);
-    for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(P, i, LG_SLOT_VEL(A) + k, counter, inject) + (-0.5f);
-    resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
+        for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(P, i, s_xy + k, counter, inject) + (-1.0f);
+    for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(P, i, s_vel + k, counter, inject) + (-0.5f);
+    if (tj) reset_trajectory(P, i, counter, inject);
+    else resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
     for (int j = 0; j < A; ++j) { P->buf.last_actions[(size_t)i * A + j] = 0.0f; P->buf.last_dof_vel[(size_t)i * A + j] = 0.0f; }
     for (int f = 0; f < c.num_feet; ++f) P->buf.feet_air_time[(size_t)i * c.num_feet + f] = 0.0f;
     P->buf.episode_length[i] = 0;
     P->buf.reset[i] = 1;
+    P->reset_mark[i] = 1;
     if (c.use_actuator_net) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int l = 0; l < 2; ++l)
@@ -422,8 +496,10 @@ __device__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int i
         org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
     }
     __syncthreads();
+    const bool tj = c.traj.enabled;
+    const int s_dof = tj ? LG_TSLOT_DOF : LG_SLOT_DOF, s_xy = tj ? LG_TSLOT_XY(A) : LG_SLOT_XY(A), s_vel = tj ? LG_TSLOT_VEL(A) : LG_SLOT_VEL(A);
     if (tid < A) {                                                 // joint j = tid
-        const float u = uni(P, i, LG_SLOT_DOF + tid, counter, inject);
+        const float u = uni(P, i, s_dof + tid, counter, inject);
         reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)i * A + tid] = make_float2(c.default_dof_pos[tid] * ((1.5f - 0.5f) * u + 0.5f), 0.0f);
         P->buf.last_actions[(size_t)i * A + tid] = 0.0f;
         P->buf.last_dof_vel[(size_t)i * A + tid] = 0.0f;
@@ -431,13 +507,14 @@ __device__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int i
         const int k = tid - A;
         float v = c.base_init_state[k];
         if (k < 3) v += org[k];
-        if (k < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * uni(P, i, LG_SLOT_XY(A) + k, counter, inject) + (-1.0f);
-        if (k >= 7) v = (0.5f - (-0.5f)) * uni(P, i, LG_SLOT_VEL(A) + (k - 7), counter, inject) + (-0.5f);
+        if (k < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * uni(P, i, s_xy + k, counter, inject) + (-1.0f);
+        if (k >= 7) v = (0.5f - (-0.5f)) * uni(P, i, s_vel + (k - 7), counter, inject) + (-0.5f);
         r[k] = v;
     } else if (tid == A + 13) {
-        resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
+        if (!tj) resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
         P->buf.episode_length[i] = 0;
         P->buf.reset[i] = 1;
+        P->reset_mark[i] = 1;
     } else if (tid < A + 14 + F) {
         P->buf.feet_air_time[(size_t)i * F + (tid - A - 14)] = 0.0f;
     }
@@ -451,6 +528,10 @@ __device__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int i
         }
     }
     __syncthreads();
+    if (tj) {                                                      // needs the new root pose: after the barrier, one lane (a serial 10-step
+        if (tid == 0) reset_trajectory(P, i, counter, inject);     // ROM integration; resets are rare)
+        __syncthreads();
+    }
 }
 
 
@@ -481,10 +562,10 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     const int env0 = blockIdx.x * TILE;
     const int nE = min(TILE, N - env0);
     const int tid = threadIdx.x;
-    __shared__ float s_acc[LG_NUM_REWARDS];
+    __shared__ float s_acc[LG_NUM_TERMS];
     __shared__ int s_cnt, s_flt;
     __shared__ int s_list[TILE];                               // envs of this tile that reset this step
-    if (tid < LG_NUM_REWARDS) s_acc[tid] = 0.0f;
+    if (tid < LG_NUM_TERMS) s_acc[tid] = 0.0f;
     if (tid == 0) { s_cnt = 0; s_flt = 0; }
 
     // ---- phase H: height scan of the pre-reset pose (LR:356-357)
@@ -516,8 +597,9 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         o3[0] = x.bav.x; o3[1] = x.bav.y; o3[2] = x.bav.z;
         o3 = P->buf.projected_gravity + 3 * (size_t)i;
         o3[0] = x.pg.x; o3[1] = x.pg.y; o3[2] = x.pg.z;
-        if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject);   // LR:348-350
-        if (c.heading_command) {                                            // LR:351-354, math.py:45-48
+        if (c.traj.enabled) tg_callback_step(P, i, counter, inject);       // LT:405-417
+        else if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject);   // LR:348-350
+        if (c.heading_command && !c.traj.enabled) {                         // LR:351-354, math.py:45-48
             V3 fwd = quat_apply(r + 3, V3{1.0f, 0.0f, 0.0f});
             float heading = atan2f(fwd.y, fwd.x);
             const float two_pi = 6.283185307179586f;
@@ -526,7 +608,16 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
             if (ang > 3.141592653589793f) ang -= two_pi;
             cmd[2] = clampf(0.5f * ang, -1.0f, 1.0f);
         }
-        if (c.push_robots && c.push_interval > 0 && (counter % c.push_interval == 0)) {   // LR:358-359,456-461
+        if (c.traj.enabled) {                                               // LT:150-160,483-486: per-env push timers
+            float tm = P->buf.push_timer[i] - c.dt;
+            if (tm <= 0.0f) {
+                const float mv = c.traj.max_push_vel_xy;
+                r[7] = (mv - (-mv)) * uni(P, i, LG_TSLOT_PUSH, counter, inject) + (-mv);
+                r[8] = (mv - (-mv)) * uni(P, i, LG_TSLOT_PUSH + 1, counter, inject) + (-mv);
+                tm = (c.traj.push_t_hi - c.traj.push_t_lo) * uni(P, i, LG_TSLOT_TIMER, counter, inject) + c.traj.push_t_lo;
+            }
+            P->buf.push_timer[i] = tm;
+        } else if (c.push_robots && c.push_interval > 0 && (counter % c.push_interval == 0)) {   // LR:358-359,456-461
             r[7] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH, counter, inject) + (-c.max_push_vel);
             r[8] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH + 1, counter, inject) + (-c.max_push_vel);
         }
@@ -542,9 +633,11 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         x.tau = P->buf.torques + (size_t)i * A; x.act = P->buf.actions + (size_t)i * A;
         x.lact = P->buf.last_actions + (size_t)i * A; x.lqd = P->buf.last_dof_vel + (size_t)i * A;
         float rew = 0.0f;                                                   // LR:189-206
-        for (int k = 0; k < LG_NUM_REWARDS; ++k) {
-            if (k == LG_REW_TERMINATION || c.rew_scale[k] == 0.0f) continue;
-            float v = reward_term(P, i, k, x) * c.rew_scale[k];
+        for (int o = 0; o < c.num_terms; ++o) {                             // active builtin and extra terms, alphabetical (LR:605-629)
+            const int k = c.term_order[o];
+            float v;
+            if (k < LG_NUM_REWARDS) v = reward_term(P, i, k, x) * c.rew_scale[k];
+            else v = xterm_value(P, i, c.xterms[k - LG_NUM_REWARDS], x) * c.xterms[k - LG_NUM_REWARDS].scale;
             rew += v;
             P->buf.episode_sums[(size_t)k * N + i] += v;
         }
@@ -557,8 +650,8 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         P->buf.rew[i] = rew;
         if (rst) {                                                          // LR:147-187
             s_list[atomicAdd(&s_cnt, 1)] = i;
-            for (int k = 0; k < LG_NUM_REWARDS; ++k)
-                if (c.rew_scale[k] != 0.0f) {
+            for (int k = 0; k < LG_NUM_TERMS; ++k)
+                if (term_scale(c, k) != 0.0f) {
                     atomicAdd(&s_acc[k], P->buf.episode_sums[(size_t)k * N + i]);
                     P->buf.episode_sums[(size_t)k * N + i] = 0.0f;
                 }
@@ -567,12 +660,14 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     __syncthreads();
     for (int q = 0; q < s_cnt; ++q) reset_env_coop(P, s_list[q], counter, inject, init_done);   // workgroup-uniform trip count
     if (s_cnt > 0) {
-        if (tid < LG_NUM_REWARDS && c.rew_scale[tid] != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
+        if (tid < LG_NUM_TERMS && term_scale(c, tid) != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
         if (tid == 0) atomicAdd(P->reset_count, s_cnt);
         if (tid == 0 && s_flt > 0) atomicAdd(P->fault_count, s_flt);
     }
 
     // ---- phase O: observations (LR:208-226), clip (LR:100-103), bookkeeping (LR:132-134)
+    const int ob = c.traj.enabled ? 9 + 2 * c.traj.N : 12;              // first joint entry: after commands[:3] | the trajectory block
+    const int s_noise = c.traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A);
     for (int idx = tid; idx < nE * O; idx += LG_TILE_THREADS) {
         const int i = env0 + idx / O, k = idx % O;
         const float *r = P->buf.root_states + (size_t)i * 13;
@@ -580,12 +675,15 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         if (k < 3) v = P->buf.base_lin_vel[3 * (size_t)i + k] * c.obs_scale_lin_vel;
         else if (k < 6) v = P->buf.base_ang_vel[3 * (size_t)i + k - 3] * c.obs_scale_ang_vel;
         else if (k < 9) v = P->buf.projected_gravity[3 * (size_t)i + k - 6];
-        else if (k < 12) v = P->buf.commands[(size_t)i * 4 + k - 9] * (k == 11 ? c.obs_scale_ang_vel : c.obs_scale_lin_vel);
-        else if (k < 12 + A) v = (P->buf.dof_state[((size_t)i * A + k - 12) * 2] - c.default_dof_pos[k - 12]) * c.obs_scale_dof_pos;
-        else if (k < 12 + 2 * A) v = P->buf.dof_state[((size_t)i * A + k - 12 - A) * 2 + 1] * c.obs_scale_dof_vel;
-        else if (k < 12 + 3 * A) v = P->buf.actions[(size_t)i * A + k - 12 - 2 * A];
-        else v = clampf(r[2] - 0.5f - P->buf.measured_heights[(size_t)i * H + k - 12 - 3 * A], -1.0f, 1.0f) * c.obs_scale_height;
-        if (c.add_noise) v += (2.0f * uni(P, i, LG_SLOT_NOISE(A) + k, counter, inject) - 1.0f) * P->noise_vec[k];
+        else if (k < ob) {
+            if (c.traj.enabled) v = (P->buf.trajectory[(size_t)i * 2 * c.traj.N + (k - 9)] - r[(k - 9) & 1]) * c.traj.obs_scale[(k - 9) & 1];   // LT:280-288
+            else v = P->buf.commands[(size_t)i * 4 + k - 9] * (k == 11 ? c.obs_scale_ang_vel : c.obs_scale_lin_vel);
+        }
+        else if (k < ob + A) v = (P->buf.dof_state[((size_t)i * A + k - ob) * 2] - c.default_dof_pos[k - ob]) * c.obs_scale_dof_pos;
+        else if (k < ob + 2 * A) v = P->buf.dof_state[((size_t)i * A + k - ob - A) * 2 + 1] * c.obs_scale_dof_vel;
+        else if (k < ob + 3 * A) v = P->buf.actions[(size_t)i * A + k - ob - 2 * A];
+        else v = clampf(r[2] - 0.5f - P->buf.measured_heights[(size_t)i * H + k - ob - 3 * A], -1.0f, 1.0f) * c.obs_scale_height;
+        if (c.add_noise) v += (2.0f * uni(P, i, s_noise + k, counter, inject) - 1.0f) * P->noise_vec[k];
         P->buf.obs[(size_t)i * O + k] = clampf(v, -c.clip_obs, c.clip_obs);
     }
     for (int idx = tid; idx < nE * A; idx += LG_TILE_THREADS) {
@@ -601,14 +699,17 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
 
 // Single-workgroup epilogue: extras["episode"], extras["time_outs"] (only refreshed when >=1 env
 // reset this step: the early return of LR:156-157 keeps the previous, stale values), terrain level mean.
-__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P) {
+__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P, int64_t counter, int inject) {
     const lg_cfg &c = P->cfg;
     const int N = c.num_envs, tid = threadIdx.x;
     const int n = *P->reset_count;
     __shared__ float s_red[256];
     if (n > 0) {
-        if (tid < LG_NUM_REWARDS)
-            P->buf.extras_episode[tid] = c.rew_scale[tid] != 0.0f ? (P->ep_accum[tid] / (float)n) / c.episode_length_s : 0.0f;
+        if (tid < LG_NUM_TERMS)
+            P->buf.extras_episode[tid] = term_scale(c, tid) != 0.0f ? (P->ep_accum[tid] / (float)n) / c.episode_length_s : 0.0f;
+        if (c.traj.enabled)                       // the reference's reset loop re-checks the hold time of EVERY env (lg_traj.h)
+            for (int i = tid; i < N; i += 256)
+                if (!P->reset_mark[i]) tg_late_resample(P, i, counter, inject);
         if (c.send_timeouts)
             for (int i = tid; i < N; i += 256) P->buf.extras_time_outs[i] = P->buf.time_out[i];
         if (c.curriculum) {
@@ -625,15 +726,17 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
     }
     __syncthreads();
     __syncthreads();
-    if (tid < LG_NUM_REWARDS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
+    if (n > 0 || c.traj.enabled)
+        for (int i = tid; i < N; i += 256) P->reset_mark[i] = 0;
+    if (tid < LG_NUM_TERMS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
     if (tid == 0) {
-        P->buf.extras_episode_acc[LG_NUM_REWARDS] += P->buf.extras_terrain_level[0];
-        P->buf.extras_episode_acc[LG_NUM_REWARDS + 1] += 1.0f;
+        P->buf.extras_episode_acc[LG_NUM_TERMS] += P->buf.extras_terrain_level[0];
+        P->buf.extras_episode_acc[LG_NUM_TERMS + 1] += 1.0f;
         P->buf.n_reset[0] = n; *P->reset_count = 0;
         const int nf = *P->fault_count;
         P->buf.n_fault[0] = nf; P->buf.fault_total[0] += nf; *P->fault_count = 0;
     }
-    if (tid < LG_NUM_REWARDS) P->ep_accum[tid] = 0.0f;
+    if (tid < LG_NUM_TERMS) P->ep_accum[tid] = 0.0f;
 }
 
 // reset_idx(env_ids) for a caller-given subset (LR:147-187): one workgroup per id.  The episode-sum means of the
@@ -645,7 +748,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_reset_ids(const DevParams *
     for (int q = blockIdx.x; q < n; q += gridDim.x) {         // workgroup-uniform
         const int i = ids[q];
         if (i < 0 || i >= N) continue;
-        if (tid < LG_NUM_REWARDS && c.rew_scale[tid] != 0.0f) {
+        if (tid < LG_NUM_TERMS && term_scale(c, tid) != 0.0f) {
             atomicAdd(P->ep_accum + tid, P->buf.episode_sums[(size_t)tid * N + i]);
             P->buf.episode_sums[(size_t)tid * N + i] = 0.0f;
         }
@@ -658,8 +761,9 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_reset_ids(const DevParams *
 __global__ void k_reset_all(const DevParams *__restrict__ P, int64_t counter, int inject, int init_done) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P->cfg.num_envs) return;
-    for (int k = 0; k < LG_NUM_REWARDS; ++k) P->buf.episode_sums[(size_t)k * P->cfg.num_envs + i] = 0.0f;
+    for (int k = 0; k < LG_NUM_TERMS; ++k) P->buf.episode_sums[(size_t)k * P->cfg.num_envs + i] = 0.0f;
     reset_env(P, i, counter, inject, init_done);
+    P->reset_mark[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -678,12 +782,12 @@ extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L,
 extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     constexpr int TILE = 16;
     hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
 }
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);
 }
 extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_ids, dim3(n < 1024 ? n : 1024), dim3(LG_TILE_THREADS), 0, s, P, ids, n, counter, inject, init_done);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
 }

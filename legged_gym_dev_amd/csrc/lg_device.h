@@ -33,6 +33,7 @@ struct DevParams {
     int32_t *reset_count;          // 1
     int32_t *fault_count;          // 1: faults consumed by the running step (block atomics), folded by k_finalize
     uint8_t *fault;                // N: set by the physics fault guard, consumed by the post-step
+    uint8_t *reset_mark;           // N: envs reset since the last k_finalize (which clears it)
     int K;                         // uniforms per env
     // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
     int n_leg_slots, n_base_spheres;

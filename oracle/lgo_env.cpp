@@ -459,6 +459,12 @@ void reset_ids(Env &e, const int32_t *ids, int n) {
         e.extras_episode[k] = (s / (float)n) / c.episode_length_s;
     }
     for (int q = 0; q < n; ++q) reset_env(e, ids[q]);
+    if (c.traj.enabled) {                                             // the generator's reset loop reaches every env (lgo_traj.cpp)
+        std::vector<uint8_t> in(e.N, 0);
+        for (int q = 0; q < n; ++q) in[ids[q]] = 1;
+        for (int i = 0; i < e.N; ++i)
+            if (!in[i]) tg_late_resample(e, i);
+    }
     if (c.curriculum) {
         float s = 0.0f;
         for (int i = 0; i < e.N; ++i) s += (float)e.terrain_levels[i];

@@ -522,3 +522,182 @@ def test_rollout_properties_at_baseline_size_on_terrain(task, z_lo, z_hi):
             env.close()
     for x, y in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------ trajectory-tracking variant
+TRAJ = "anymal_c_flat_trajectory"
+
+
+def test_hip_replays_reference_trajectory_steps():
+    """the HIP post-step with lg_cfg.traj enabled against six steps of the reference's own
+    LeggedRobotTrajectory / AnymalTrajectory / TrajectoryGenerator (tests/golden/anymal_c_flat_trajectory.npz): generator
+    resamples (in the callback and on the reset loop's re-check), ROM steps, interpolated trajectory, per-env push timers,
+    tracking_rom / differential_error through the generic term table, the 65-wide observation, resets with the random
+    trajectory start offset."""
+    z, meta = harness.load_fixture(TRAJ)
+    setup, _ = harness.make_setup(TRAJ, z, meta)
+    env = harness.HipHandle(setup)
+    try:
+        harness.replay_trajectory_fixture(env, z, meta)
+    finally:
+        env.close()
+
+
+def test_trajectory_env_full_step_philox_matches_oracle(oracle_built):
+    """lg_step of the trajectory env with its own Philox streams vs the oracle on the same seed over 30 policy steps (clocks
+    scattered so that generator resamples, ROM steps, pushes, time-outs and resets all occur): masks, counters and the
+    generator's discrete state bit-exact, fp32 state within tolerance (re-glued every step)."""
+    z, meta = harness.load_fixture(TRAJ)
+    cfg = harness.make_cfg(TRAJ)
+    n = cfg.env.num_envs = 128
+    from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+    from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+    cm = compile_model(resolve_model("", "anymal_c"))
+
+    def mk():
+        return EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), seed=17, extra_terms=harness.extra_terms_for(cfg))
+    hip, ora = harness.HipHandle(mk()), oracle_built.OracleEnv(mk())
+    try:
+        rng = np.random.default_rng(6)
+        tg = np.zeros((n, capi_TG_STRIDE()), np.float32)
+        o = _tgf()
+        tg[:, o["ramp_v_end"][0]:o["ramp_v_end"][0] + 2] = rng.uniform(-0.35, 0.35, (n, 2))
+        for e in (hip, ora):
+            e.set("tg_state", tg)
+            e.set("push_timer", rng.uniform(0.0, 0.5, n).astype(np.float32) if e is hip else hip.get("push_timer"))
+            e.set_step_counter(0)
+            e.inject(0)
+            e.call("reset_all")
+        for key in ("tg_state", "tg_traj", "root_states", "dof_state", "prev_error"):
+            np.testing.assert_allclose(hip.get(key), ora.get(key), rtol=1e-6, atol=1e-6, err_msg=f"after reset_all: {key}")
+        ep = rng.integers(0, 1000, n)
+        ep[:4] = [1000, 1001, 999, 3]
+        for e in (hip, ora):
+            e.set("episode_length", ep)
+        seen = {"reset": 0, "pushed": 0, "resampled": 0, "rom": 0}
+        for t in range(30):
+            act = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+            before = ora.get("tg_state").copy()
+            pt_before = ora.get("push_timer").copy()
+            hip.step(act)
+            ora.step(act)
+            for key in ("reset", "time_out", "episode_length"):
+                np.testing.assert_array_equal(hip.get(key), ora.get(key), err_msg=f"step {t} {key}")
+            assert int(hip.get("n_reset")[0]) == int(ora.get("n_reset")[0])
+            gh, go = hip.get("tg_state"), ora.get("tg_state")
+            for name in ("k", "stationary"):
+                np.testing.assert_array_equal(gh[:, o[name][0]], go[:, o[name][0]], err_msg=f"step {t} generator {name}")
+            np.testing.assert_allclose(gh, go, rtol=2e-5, atol=2e-5, err_msg=f"step {t} generator state")
+            for key, tol in (("obs", 2e-3), ("rew", 2e-3), ("root_states", 1e-3), ("dof_state", 2e-3), ("trajectory", 2e-5),
+                             ("tg_traj", 2e-5), ("prev_error", 2e-4), ("push_timer", 1e-6), ("torques", 5e-3)):
+                np.testing.assert_allclose(hip.get(key), ora.get(key), rtol=tol, atol=tol, err_msg=f"step {t} {key}")
+            rst = ora.get("reset").astype(bool)
+            seen["reset"] += int(rst.sum())
+            seen["pushed"] += int((ora.get("push_timer") > pt_before).sum())
+            seen["resampled"] += int(((go[:, o["t_final"][0]] != before[:, o["t_final"][0]]) & ~rst).sum())
+            seen["rom"] += int(((go[:, o["k"][0]] != before[:, o["k"][0]]) & ~rst).sum())
+            for key in ("root_states", "dof_state", "lstm_h", "lstm_c", "last_dof_vel", "last_root_vel", "feet_air_time",
+                        "episode_sums", "tg_state", "tg_traj", "trajectory", "prev_error", "push_timer"):
+                hip.set(key, ora.get(key))
+        assert seen["reset"] > 5 and seen["pushed"] > 20 and seen["resampled"] > 10 and seen["rom"] > 500, seen
+    finally:
+        hip.close()
+        ora.close()
+
+
+def capi_TG_STRIDE():
+    from legged_gym_dev_amd import capi
+    return capi.TG_STRIDE
+
+
+def _tgf():
+    from legged_gym_dev_amd import capi
+    return capi.TG_FIELDS
+
+
+def test_declared_extra_term_equals_the_builtin_it_mirrors(oracle_built):
+    """The extension point for reward terms (the reference's _reward_<name> methods, legged_robot.py:605-629): a term declared
+    as data -- exp(-|cmd_xy - v_xy|^2 / sigma) under the name tracking_xy, plus a weighted square of the projected gravity --
+    must produce the values of the builtin tracking_lin_vel / orientation terms, get its own episode sum and extras entry,
+    and take its alphabetical place in the reward sum.  HIP == oracle, and extra == builtin within fp32 rounding."""
+    from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+    from legged_gym_dev_amd.envs.base.reward_terms import ExpNegWeightedSqErr, WeightedSq
+    from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+    cfg = harness.make_cfg("anymal_c_allrewards")
+    n = cfg.env.num_envs = 96
+    cfg.rewards.scales.tracking_xy = 1.0          # same scale as tracking_lin_vel
+    cfg.rewards.scales.gravity_xy = -0.5          # same scale as orientation
+    terms = {"tracking_xy": ExpNegWeightedSqErr("commands", "base_lin_vel", weights=[1.0, 1.0], sigma=cfg.rewards.tracking_sigma),
+             "gravity_xy": WeightedSq("projected_gravity", weights=[1.0, 1.0])}
+    cm = compile_model(resolve_model("", "anymal_c"))
+
+    def mk():
+        return EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), seed=3, extra_terms=terms)
+    setup = mk()
+    assert setup.xterm_names == ["tracking_xy", "gravity_xy"]
+    names = sorted(k for k in setup.reward_scales if k != "termination")
+    assert [setup.term_row[k] for k in names] == setup.term_order and names.index("tracking_xy") == names.index("tracking_lin_vel") + 1
+    hip, ora = harness.HipHandle(setup), oracle_built.OracleEnv(mk())
+    try:
+        rng = np.random.default_rng(1)
+        for e in (hip, ora):
+            e.set_step_counter(0)
+            e.inject(0)
+            e.call("reset_all")
+        for t in range(5):
+            act = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+            hip.step(act)
+            ora.step(act)
+            np.testing.assert_allclose(hip.get("rew"), ora.get("rew"), rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(hip.get("episode_sums"), ora.get("episode_sums"), rtol=2e-3, atol=2e-3)
+            es = hip.get("episode_sums")
+            row = setup.term_row
+            live = ~hip.get("reset").astype(bool)
+            np.testing.assert_allclose(es[row["tracking_xy"]][live], es[row["tracking_lin_vel"]][live], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(es[row["gravity_xy"]][live], es[row["orientation"]][live], rtol=1e-5, atol=1e-7)
+            assert np.abs(es[row["tracking_xy"]]).sum() > 0
+            for key in ("root_states", "dof_state", "last_dof_vel", "last_root_vel", "feet_air_time", "episode_sums", "commands"):
+                hip.set(key, ora.get(key))
+        np.testing.assert_allclose(hip.get("extras_episode"), ora.get("extras_episode"), rtol=1e-3, atol=1e-6)
+    finally:
+        hip.close()
+        ora.close()
+
+
+def test_trajectory_task_trains_through_the_registry(tmp_path):
+    """anymal_c_flat_trajectory as a user runs it: task_registry.make_env builds AnymalTrajectory (65 observations, reference
+    attribute names), the runner trains two iterations with the authors' tracking reward, a caller resets a subset."""
+    import copy
+    import torch
+    from legged_gym_dev_amd.envs import task_registry
+    from legged_gym_dev_amd.utils import get_args
+    from legged_gym_dev_amd.utils.helpers import class_to_dict
+    from legged_gym_dev_amd.rl.runner import OnPolicyRunner
+    args = get_args(["--task", TRAJ, "--num_envs", "256", "--headless"])
+    args.sim_device = args.rl_device = "cuda:0"
+    env_cfg, train_cfg = task_registry.get_cfgs(TRAJ)
+    env_cfg, train_cfg = copy.deepcopy(env_cfg), copy.deepcopy(train_cfg)
+    env_cfg.rewards.scales.tracking_rom = 6.0
+    env_cfg.rewards.scales.differential_error = -0.5
+    env, _ = task_registry.make_env(name=TRAJ, args=args, env_cfg=env_cfg)
+    try:
+        assert type(env).__name__ == "AnymalTrajectory" and env.num_obs == 65 and not hasattr(env, "commands")
+        assert env.trajectory.shape == (256, 10, 2) and env.prev_error.shape == (256, 2) and env.time_until_next_push.shape == (256, 1)
+        assert float(env.time_until_next_push.min()) >= 0.5 and float(env.time_until_next_push.max()) <= 10.0
+        assert set(env.episode_sums) == {"differential_error", "feet_air_time", "orientation", "termination", "torques", "tracking_rom"}
+        runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device="cuda:0")
+        runner.learn(2, init_at_random_ep_len=True)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(runner.ppo.t["params"]).all()) and bool(torch.isfinite(env.obs_buf).all())
+        # the trajectory block of the observation is the interpolated window relative to the robot (noise scale 0 there)
+        want = (env.trajectory - env.root_states[:, None, :2]).reshape(256, 20)
+        live = ~env.reset_buf                      # reset envs observe the pre-reset window against the new pose (reference quirk)
+        torch.testing.assert_close(env.obs_buf[live, 9:29], want[live].clamp(-100, 100), rtol=1e-5, atol=1e-6)
+        assert float(env.traj_gen.t.min()) > -1.01 and float(env.traj_gen.weights.sum(1).sub(1).abs().max()) < 1e-5
+        assert "rew_tracking_rom" in env.extras["episode"] and int(env.fault_total[0]) == 0
+        env.reset_idx(torch.tensor([3, 5, 200], device="cuda:0"))
+        torch.cuda.synchronize()
+        assert (env.episode_length_buf[[3, 5, 200]] == 0).all() and float(env.traj_gen.k[[3, 5, 200]].abs().max()) == 0.0
+        runner.ppo.close()
+    finally:
+        env.close()
