@@ -132,6 +132,7 @@ typedef struct lg_xterm {
 #define LG_TG_SIN_OFF 20   /* 2 */
 #define LG_TG_SIN_MEAN 22  /* 2 */
 #define LG_TG_STATIONARY 24 /* 0 | 1 */
+#define LG_TG_V 25         /* 2: the mixed input of the last evaluation (TrajectoryGenerator.v, what dataset rollouts log) */
 #define LG_TG_STRIDE 28
 typedef struct lg_traj_cfg {
     int32_t enabled, N, dN, randomize_rom_distance;

@@ -28,7 +28,7 @@ SIGNALS = {"zero": (0, 8), "base_lin_vel": (1, 3), "base_ang_vel": (2, 3), "proj
 TRAJ_MAX_PTS, TG_NDRAW, TG_STRIDE = 17, 20, 28
 TG_FIELDS = {"weights": (0, 4), "t_final": (4, 1), "t": (5, 1), "k": (6, 1), "const": (7, 2), "extreme": (9, 2),
              "ramp_t_start": (11, 1), "ramp_v_start": (12, 2), "ramp_v_end": (14, 2), "sin_mag": (16, 2), "sin_freq": (18, 2),
-             "sin_off": (20, 2), "sin_mean": (22, 2), "stationary": (24, 1)}                        # LG_TG_* offsets
+             "sin_off": (20, 2), "sin_mean": (22, 2), "stationary": (24, 1), "v": (25, 2)}                        # LG_TG_* offsets
 
 
 def tslots(A):

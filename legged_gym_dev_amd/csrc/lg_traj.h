@@ -108,6 +108,7 @@ __device__ inline void tg_callback_step(const DevParams *P, int i, int64_t count
     if (tt > s[LG_TG_T_FINAL]) tg_resample(P, i, LG_TSLOT_TG, counter, inject);
     float v[2];
     tg_input(P, i, tt, v);
+    s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];                      // self.v (RD:579-580)
     if (tt >= s[LG_TG_K] * t.rom_dt - 1e-5f) tg_rom_step(P, i, v);
     s[LG_TG_T] = tt + P->cfg.dt;
     tg_interpolate(P, i);
@@ -129,6 +130,7 @@ __device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y,
     for (int it = 0; it < t.N * t.dN; ++it) {
         float v[2];
         tg_input(P, i, s[LG_TG_T], v);
+        s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];
         tg_rom_step(P, i, v);
         s[LG_TG_T] += t.rom_dt;
     }
@@ -137,6 +139,9 @@ __device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y,
 // the reset loop's get_input_t reaches every env (RD:579): see legged_hip.h LG_TSLOT_RTG
 __device__ inline void tg_late_resample(const DevParams *P, int i, int64_t counter, int inject) {
 #pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
-    const float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
+    float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
     if (s[LG_TG_T] > s[LG_TG_T_FINAL]) tg_resample(P, i, LG_TSLOT_RTG(P->cfg.num_actions), counter, inject);
+    float v[2];                                                    // and leaves self.v evaluated at the env's new time
+    tg_input(P, i, s[LG_TG_T], v);
+    s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];
 }

@@ -30,6 +30,19 @@ class _TrajGenView:
         return self._t["trajectory"]
 
 
+class _RomView:
+    """SingleInt2D as dataset / evaluation code uses it (rom_dynamics.py:182-212): dimensions, dt, proj_z."""
+    n, m = 2, 2
+
+    def __init__(self, tj, device):
+        self.dt = tj["rom_dt"]
+        self.v_min, self.v_max = torch.tensor(tj["v_min"], device=device), torch.tensor(tj["v_max"], device=device)
+
+    @staticmethod
+    def proj_z(x):
+        return x[..., :2]
+
+
 class LeggedRobotTrajectory(LeggedRobot):
     def extra_reward_terms(self):
         cfg = self.cfg
@@ -47,6 +60,7 @@ class LeggedRobotTrajectory(LeggedRobot):
         self.time_until_next_push = t["push_timer"].view(self.num_envs, 1)
         self.trajectory_scale = torch.tensor(tj["obs_scale"], device=self.device).repeat(tj["N"], 1)
         self.traj_gen = _TrajGenView(self)
+        self.rom = self.traj_gen.rom = _RomView(tj, self.device)
         self.tracking_sigma = float(self.cfg.rewards.tracking_sigma)
         self.max_rom_distance = torch.tensor(tj["max_rom_dist"], device=self.device)
         self.zero_rom_dist_llh = tj["zero_rom_dist_llh"]
@@ -59,3 +73,9 @@ class LeggedRobotTrajectory(LeggedRobot):
         off = capi.TG_FIELDS["ramp_v_end"][0]
         t["tg_state"][:, off:off + 2].copy_(ramp[lo:lo + self.num_envs])
         t["push_timer"].copy_(timers[lo:lo + self.num_envs, 0])
+
+    def get_state(self):
+        """(base pose 7, joint positions, base twist 6, joint velocities): the state vector dataset rollouts record
+        (deep_tube_learning/data_collection_trajectory.py:25-26; HopperTrajectory.get_state hopper_trajectory.py:284)."""
+        b = self.root_states
+        return torch.cat((b[:, :7], self.dof_pos, b[:, 7:], self.dof_vel), dim=1)

@@ -218,7 +218,8 @@ def make_traj_case(mods, name, n_steps, seed):
                 "tg_ramp_v_start": tgen.ramp_v_start.numpy().copy(), "tg_ramp_v_end": tgen.ramp_v_end.numpy().copy(),
                 "tg_sin_mag": tgen.sin_mag.numpy().copy(), "tg_sin_freq": tgen.sin_freq.numpy().copy(),
                 "tg_sin_off": tgen.sin_off.numpy().copy(), "tg_sin_mean": tgen.sin_mean.numpy().copy(),
-                "tg_traj": tgen.trajectory.numpy().copy(), "tg_stationary": tgen.stationary_inds.numpy().copy()}
+                "tg_traj": tgen.trajectory.numpy().copy(), "tg_stationary": tgen.stationary_inds.numpy().copy(),
+                "tg_v": tgen.v.numpy().copy()}
 
     def snap():
         d = {"root_states": st["root_states"].numpy().copy(), "dof_state": st["dof_state"].numpy().copy().reshape(N, A, 2),

@@ -60,6 +60,10 @@ static void tg_input(const Env &e, int i, float tt, float v[2]) {
         if (s[LG_TG_STATIONARY] != 0.0f) v[d] = 0.0f;                        // RD:580
     }
 }
+static void tg_keep_v(Env &e, int i, const float v[2]) {                     // self.v (RD:579-580)
+    e.tg_state[(size_t)i * LG_TG_STRIDE + LG_TG_V] = v[0];
+    e.tg_state[(size_t)i * LG_TG_STRIDE + LG_TG_V + 1] = v[1];
+}
 
 // RD:578-592: one ROM step of env i: z+ = A z + B v with A = I, B = rom_dt I (SingleInt2D.f RD:192-193), window shifted by one
 static void tg_rom_step(Env &e, int i, const float v[2]) {
@@ -94,6 +98,7 @@ void tg_callback_step(Env &e, int i) {
     if (tt > s[LG_TG_T_FINAL]) tg_resample(e, i, LG_TSLOT_TG);             // get_input_t RD:560-561 (every env, every step)
     float v[2];
     tg_input(e, i, tt, v);
+    tg_keep_v(e, i, v);
     if (tt >= s[LG_TG_K] * t.rom_dt - 1e-5f) tg_rom_step(e, i, v);         // RD:572
     s[LG_TG_T] = tt + e.cfg.dt;                                             // RD:574 (dt_loop = env dt)
     tg_interpolate(e, i);
@@ -114,6 +119,7 @@ void tg_reset(Env &e, int i, const float z0[2]) {
     for (int it = 0; it < t.N * t.dN; ++it) {                               // step_rom_idx(idx, increment_rom_time=True)
         float v[2];
         tg_input(e, i, s[LG_TG_T], v);
+        tg_keep_v(e, i, v);
         tg_rom_step(e, i, v);
         s[LG_TG_T] += t.rom_dt;
     }
@@ -124,6 +130,9 @@ void tg_reset(Env &e, int i, const float z0[2]) {
 void tg_late_resample(Env &e, int i) {
     const float *s = &e.tg_state[(size_t)i * LG_TG_STRIDE];
     if (s[LG_TG_T] > s[LG_TG_T_FINAL]) tg_resample(e, i, LG_TSLOT_RTG(e.A));
+    float v[2];                                                              // and leaves self.v evaluated at the env's new time
+    tg_input(e, i, s[LG_TG_T], v);
+    tg_keep_v(e, i, v);
 }
 
 }  // namespace lgo

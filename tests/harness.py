@@ -199,7 +199,7 @@ def _tg_rows(z, prefix, n):
     key = {"weights": "tg_weights", "t_final": "tg_t_final", "t": "tg_t", "k": "tg_k", "const": "tg_const", "extreme": "tg_extreme",
            "ramp_t_start": "tg_ramp_t_start", "ramp_v_start": "tg_ramp_v_start", "ramp_v_end": "tg_ramp_v_end",
            "sin_mag": "tg_sin_mag", "sin_freq": "tg_sin_freq", "sin_off": "tg_sin_off", "sin_mean": "tg_sin_mean",
-           "stationary": "tg_stationary"}
+           "stationary": "tg_stationary", "v": "tg_v"}
     for name, (off, w) in capi.TG_FIELDS.items():
         rows[:, off:off + w] = np.asarray(z[prefix + key[name]], np.float32).reshape(n, w)
     return rows

@@ -103,3 +103,39 @@ def test_play_script_runs(tmp_path, monkeypatch):
     m = scipy.io.loadmat(str(tmp_path / "play_data.mat"))
     assert set(("cmd", "action", "pos", "quat", "dof", "vel", "omega", "ddof", "torque")) <= set(m)
     assert os.path.exists(tmp_path / "logs" / train_cfg.runner.experiment_name / "exported" / "policies" / "policy_1.pt")
+
+
+def test_trajectory_dataset_rollout():
+    """SURVEY.md 8(f) f3, the dataset side: the reference's rollout loop (deep_tube_learning/data_collection_trajectory.py:97-183)
+    on the HIP trajectory env -- records at the ROM rate, shapes and bookkeeping as the tube-learning stage expects them."""
+    import copy
+    from legged_gym_dev_amd.envs import task_registry
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "legged_gym_dev_amd", "scripts"))
+    import collect_trajectory_data as ctd
+    args = _args("anymal_c_flat_trajectory", 64)
+    env_cfg, train_cfg = task_registry.get_cfgs(args.task)
+    env_cfg = copy.deepcopy(env_cfg)
+    env_cfg.env.num_envs = 64
+    env, _ = task_registry.make_env(name=args.task, args=args, env_cfg=env_cfg)
+    try:
+        A = env.num_actions
+        policy = lambda obs: torch.zeros(obs.shape[0], A, device=obs.device)      # stand still: few falls
+        recs = ctd.collect(env, policy, epochs=2, episode_length_s=1.5, save_debugging_data=True)
+        assert len(recs) == 2
+        r = recs[-1]
+        T = int(1.5 / env.rom.dt)
+        assert r["z"].shape == (64, T + 1, 2) and r["v"].shape == (64, T, 2) and r["pz_x"].shape == (64, T + 1, 2)
+        assert r["done"].shape == (64, T) and r["x"].shape == (64, T + 1, 7 + A + 6 + A)
+        assert np.isfinite(r["z"]).all() and np.isfinite(r["x"]).all()
+        assert np.abs(r["v"]).max() <= 0.35 + 1e-6                                # ROM input bounds (rom.v_max)
+        np.testing.assert_array_equal(r["pz_x"], r["x"][:, :, :2])                 # proj_z = base xy
+        # between two records every ROM made exactly one step: the recorded ROM state moves by at most rom_dt * v_max per axis
+        live = ~r["done"]
+        dz = np.abs(np.diff(r["z"], axis=1))[live]
+        assert dz.max() <= 0.35 * env.rom.dt * 1.5 + 1e-5, dz.max()
+        # a terminated env restarts with zero tracking error
+        if r["done"].any():
+            i, t = np.argwhere(r["done"])[0]
+            np.testing.assert_array_equal(r["z"][i, t + 1], r["pz_x"][i, t + 1])
+    finally:
+        env.close()
