@@ -29,6 +29,7 @@ MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_
 MFMA_BF16_PEAK_TF = 2500.0     # bf16 MFMA dense peak (MI355X_MICROARCH.md); the split-bf16 GEMM issues 6 bf16 MFMAs per
 MFMA_X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32 product block, so its fp32-equivalent ceiling is 2500 / 6 = 416.7 TFLOP/s
 BYTES_PER_ENV_STEP = 4200.0    # flat ANYmal, fused-step algorithmic bytes
+PMC_FILE = "r02_pmc_traffic.json" if os.path.isfile(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
 
 
 def macs_per_sample(obs, hidden, actions):
@@ -118,7 +119,7 @@ def gemm_roofline(runner, hidden, reps=8):
     ach = flops / (ms * 1e-3) / 1e12
     traffic = None                                  # HBM bytes per minibatch group from the committed PMC passes
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             pm = json.load(f)
         if pm.get("policy_hidden") == list(hidden):
             traffic = pm["gemm_group_bytes_per_minibatch"]
@@ -175,7 +176,7 @@ def env_roofline(env, reps=50):
     gbs = BYTES_PER_ENV_STEP * env.num_envs / (ms * 1e-3) / 1e9
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             traffic = json.load(f)["env_step_bytes_per_call"]
     except (OSError, ValueError, KeyError):
         pass
@@ -185,9 +186,10 @@ def env_roofline(env, reps=50):
 
 
 def cpu_baseline(num_envs, hidden):
-    """Own CPU restatement (oracle/: C++ env step with OpenMP + torch PPO), one bounded sample:
-    a 24-step rollout on `num_envs` envs plus one epoch (4 minibatches) of the update, scaled to the
-    5-epoch iteration.  kind = "port": PhysX / rsl_rl are absent, this is not the reference's CPU path."""
+    """Own CPU restatement (oracle/: C++ env step with OpenMP + torch PPO) timed on ONE WHOLE PPO iteration of the same
+    workload: the 24-step rollout on `num_envs` envs (policy forward + env step) and the full update, 5 epochs x 4
+    minibatches of forward + loss + backward + clip + Adam.  kind = "port": PhysX / rsl_rl are absent, this is not the
+    reference's CPU path."""
     import numpy as np
     from oracle import oracle_lib, ppo_torch
     from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg
@@ -200,31 +202,34 @@ def cpu_baseline(num_envs, hidden):
     cm = compile_model(resolve_model("", "anymal_c"))
     env = oracle_lib.OracleEnv(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), seed=1))
     env.call("reset_all")
-    T, A, O, TS = 24, 12, 48, 4                     # TS of the 24 rollout steps are actually run
+    T, A, O, E, MB = 24, 12, 48, 5, 4
     ac = ppo_torch.ActorCritic(O, O, A, hidden, hidden)
     algo = ppo_torch.PPO(ac)
-    obs = torch.from_numpy(env.buf["obs"]).clone()
+    st_obs, st_act, st_mu = torch.zeros(T, num_envs, O), torch.zeros(T, num_envs, A), torch.zeros(T, num_envs, A)
     t0 = time.perf_counter()
     with torch.no_grad():
-        for t in range(TS):
+        for t in range(T):
             obs = torch.from_numpy(env.buf["obs"]).clone()
             act = ac.act(obs)
             ac.evaluate(obs)
+            st_obs[t], st_act[t], st_mu[t] = obs, act, ac.action_mean
             env.step(act.numpy())
-    t_roll = (time.perf_counter() - t0) * T / TS
-    R = T * num_envs // 4
-    o = obs.repeat((R + num_envs - 1) // num_envs, 1)[:R] + 0.01 * torch.randn(R, O)
-    with torch.no_grad():
-        mu = ac.actor(o)
+    t_roll = time.perf_counter() - t0
+    R = T * num_envs // MB
+    o, a, m = st_obs.reshape(T * num_envs, O), st_act.reshape(T * num_envs, A), st_mu.reshape(T * num_envs, A)
+    perm = torch.randperm(T * num_envs)
     t0 = time.perf_counter()
-    algo.step_minibatch(o, o, mu + 0.1, torch.zeros(R, 1), torch.randn(R, 1), torch.randn(R, 1),
-                        torch.zeros(R, 1), mu, torch.ones(R, A))
-    t_mb = time.perf_counter() - t0
+    for _ in range(E):
+        for mb in range(MB):
+            idx = perm[mb * R:(mb + 1) * R]
+            algo.step_minibatch(o[idx], o[idx], a[idx], torch.zeros(R, 1), torch.randn(R, 1), torch.randn(R, 1),
+                                torch.zeros(R, 1), m[idx], torch.ones(R, A))
+    t_upd = time.perf_counter() - t0
     env.close()
-    total = t_roll + 20 * t_mb
+    total = t_roll + t_upd
     return {"value": round(T * num_envs / total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{TS} of 24 rollout steps x {num_envs} envs (oracle C++/OpenMP env + torch policy, scaled x{T // TS}: "
-                      f"{t_roll:.2f}s) + 1 of 20 minibatch updates ({t_mb:.2f}s, scaled x20); {cores} threads"}
+            "sample": f"one whole PPO iteration: {T} rollout steps x {num_envs} envs (oracle C++/OpenMP env + torch policy: {t_roll:.2f}s) "
+                      f"+ {E * MB} minibatch updates of {R} rows ({t_upd:.2f}s); {cores} threads"}
 
 
 def rank_environments(n, port, base=None):
@@ -311,8 +316,16 @@ def main():
                       "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden, "parallelism": f"env-shard x{world}",
                       "rollout_ms": round(1e3 * t_roll / args.steps, 3),
                       "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
+    # what the number was measured on: how often the random-init policy makes robots fall, and whether the
+    # physics fault guard ever fired (it must not)
+    ep_done = int(runner.ppo.t["ep_ring_count"].cpu())
+    steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2)
+    out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
+    out["config"]["physics_fault_resets"] = int(env.fault_total.cpu())
     if rank == 0 and world == 1:
         out["roofline"] = gemm_roofline(runner, hidden)
+        out["roofline"]["traffic_source"] = ("committed PMC passes of this command (profiles/" + PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / "
+                                             "WRITE_SIZE in separate runs); not collected during this run")
         out["roofline_env_step"] = env_roofline(env)
         if tuple(hidden) != (128, 64, 32) and not args.no_alt:
             env.close()

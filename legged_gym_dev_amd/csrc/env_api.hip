@@ -160,7 +160,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     {
         const int npts = cfg->traj.enabled ? cfg->traj.N * cfg->traj.dN + 1 : 1, nobs = cfg->traj.enabled ? cfg->traj.N : 1;
         DA(b.tg_state, (size_t)N * LG_TG_STRIDE); DA(b.tg_traj, (size_t)N * npts * 2); DA(b.trajectory, (size_t)N * nobs * 2);
-        DA(b.prev_error, (size_t)N * 2); DA(b.push_timer, N); DA(h.reset_mark, N);
+        DA(b.prev_error, (size_t)N * 2); DA(b.push_timer, N); DA(h.reset_mark, N); DA(h.dbg_cycles, 64 * 8);
     }
     DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N);
     DA(h.ep_accum, LG_NUM_TERMS); DA(h.reset_count, 1); DA(h.fault, N);
@@ -238,6 +238,11 @@ int lg_post_physics_step(lg_ctx *c) {
 int lg_reset_all(lg_ctx *c) {
     lgk_reset_all(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
     return chk_launch();
+}
+int lg_debug_post_step_cycles(lg_ctx *c, unsigned long long *out /* host, 64 x 8 */) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->h.dbg_cycles, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
 }
 int lg_reset_ids(lg_ctx *c, const int32_t *ids, int n) {        // legged_robot.py:147-187
     if (n < 0 || (n > 0 && !ids)) { g_err = "lg_reset_ids: bad id list"; return -1; }

@@ -18,8 +18,8 @@ __global__ void k_set_actions(const DevParams *__restrict__ P, const float *__re
 // Actuator net, wide form: 8 lanes per (env, joint) row, lane k owns hidden unit k of both LSTM
 // layers (its 4 gate rows: 112 weights + lin_w[k], read from LDS).  The 8 hidden values of a row are
 // exchanged with width-8 shuffles; the state (2, N*A, 8) is read/written 4 B per lane, fully coalesced.
-__device__ __forceinline__ float fsigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ftanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float fsigm(float x) { return frcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * frcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // One actuator-net update of lane k (hidden unit k of both layers) of a row; w = the 972 weights in LDS.
 // Returns the row's output sum (reduced over the 8 lanes by butterflies).
@@ -567,6 +567,8 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     __shared__ int s_list[TILE];                               // envs of this tile that reset this step
     if (tid < LG_NUM_TERMS) s_acc[tid] = 0.0f;
     if (tid == 0) { s_cnt = 0; s_flt = 0; }
+#define STAMP(k) do { if (tid == 0 && blockIdx.x < 64) P->dbg_cycles[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
 
     // ---- phase H: height scan of the pre-reset pose (LR:356-357)
     if (c.measure_heights) {
@@ -578,6 +580,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         }
     }
     __syncthreads();
+    STAMP(1);
 
     // ---- phase A: one lane per env: LR:111-129
     if (tid < nE) {
@@ -658,7 +661,9 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         }
     }
     __syncthreads();
+    STAMP(2);
     for (int q = 0; q < s_cnt; ++q) reset_env_coop(P, s_list[q], counter, inject, init_done);   // workgroup-uniform trip count
+    STAMP(3);
     if (s_cnt > 0) {
         if (tid < LG_NUM_TERMS && term_scale(c, tid) != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
         if (tid == 0) atomicAdd(P->reset_count, s_cnt);
@@ -695,6 +700,8 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
         const int i = env0 + idx / 6, k = idx % 6;
         P->buf.last_root_vel[(size_t)i * 6 + k] = P->buf.root_states[(size_t)i * 13 + 7 + k];
     }
+    STAMP(4);
+#undef STAMP
 }
 
 // Single-workgroup epilogue: extras["episode"], extras["time_outs"] (only refreshed when >=1 env

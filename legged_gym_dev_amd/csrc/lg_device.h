@@ -34,6 +34,7 @@ struct DevParams {
     int32_t *fault_count;          // 1: faults consumed by the running step (block atomics), folded by k_finalize
     uint8_t *fault;                // N: set by the physics fault guard, consumed by the post-step
     uint8_t *reset_mark;           // N: envs reset since the last k_finalize (which clears it)
+    unsigned long long *dbg_cycles; // 8 per post-step workgroup (first 64 workgroups): s_memtime at the phase boundaries (tools/post_step_phases.py)
     int K;                         // uniforms per env
     // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
     int n_leg_slots, n_base_spheres;
@@ -116,6 +117,17 @@ __device__ __forceinline__ V3 quat_apply(const float *q, V3 b) {
     return b + q[3] * t + cross(qv, t);
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// 1 / x as ONE v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal: hipcc expands it to the full
+// v_div_scale / v_div_fmas / v_div_fixup sequence (~10 instructions) -- 60 of them per control-loop round in the actuator net.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// lane ^ 1 / lane ^ 2 exchange inside a quad as a DPP operand modifier (quad_perm): no LDS crossbar round trip, unlike the
+// ds_bpermute_b32 that __shfl_xor compiles to.  A lone wave per SIMD cannot hide that latency.
+__device__ __forceinline__ float quad_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+}
 
 // ------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c[4]) {

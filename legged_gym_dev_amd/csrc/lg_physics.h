@@ -8,7 +8,7 @@
 //
 // Mapping to CDNA4: a wave64 holds 64/L environments; the L lanes of an environment own one leg
 // chain each (J revolute joints, unrolled; S, U, 1/D, u and the base inverse inertia in VGPRs), and
-// meet only at the floating base through L-lane butterfly sums (DPP via __shfl_xor): 27 floats for
+// meet only at the floating base through L-lane butterfly sums (DPP quad_perm operands): 27 floats for
 // the articulated base inertia + bias, 6 floats per sweep.  Per-leg model constants, per-link tiles,
 // contact-slot and joint-limit records live in LDS columns (field-major, one column per lane:
 // conflict-free).  No barriers inside a step, no divergence between legs; contact work walks each
@@ -111,9 +111,10 @@ __device__ __forceinline__ M3 quat_to_mat(const float *q) {
 }
 
 template <int L>
-__device__ __forceinline__ float leg_sum(float x) {     // sum over the L lanes of one environment
-#pragma unroll
-    for (int m = 1; m < L; m <<= 1) x += __shfl_xor(x, m);
+__device__ __forceinline__ float leg_sum(float x) {     // sum over the L lanes of one environment (L = 2 or 4: inside a quad)
+    static_assert(L == 2 || L == 4, "legs of an environment sit in one quad of lanes");
+    x += quad_xor1(x);
+    if (L == 4) x += quad_xor2(x);
     return x;
 }
 template <int L>
@@ -174,7 +175,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
 #define LK(j, f) lkt[((j) * LG_LK_NF + (f)) * 64 + lane]
     Sv S[J], U[J];
     float iD[J], u[J];
-    const float inv_dt = __frcp_rn(dt);
+    const float inv_dt = frcp(dt);
     {   // outward kinematics
         M3 Rpar = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
         V3 ppar = {0.f, 0.f, 0.f};
@@ -229,7 +230,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
         const float Dj = sdot(S[j], U[j]);
         u[j] = (tau[j] - jt[28] * qd[j]) - sdot(S[j], pA);
         float Uv[6] = {U[j].w.x, U[j].w.y, U[j].w.z, U[j].v.x, U[j].v.y, U[j].v.z};
-        const float invD = __frcp_rn(Dj);
+        const float invD = frcp(Dj);
         iD[j] = invD;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -361,14 +362,14 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
         }
         if (valid) {
-            CF(si, 6) = Wc[0][0] > 1e-9f ? __frcp_rn(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
-            CF(si, 9) = Wc[1][1] > 1e-9f ? __frcp_rn(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
-            CF(si, 11) = Wc[2][2] > 1e-9f ? __frcp_rn(Wc[2][2]) : 0.f;
+            CF(si, 6) = Wc[0][0] > 1e-9f ? frcp(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
+            CF(si, 9) = Wc[1][1] > 1e-9f ? frcp(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
+            CF(si, 11) = Wc[2][2] > 1e-9f ? frcp(Wc[2][2]) : 0.f;
         }
     }
     const int n_base_active = (int)leg_sum<L>((float)__popc(amask >> LG_MAX_LEG_SLOTS));
     const int n_leg_active = __popc(amask & ((1u << LG_MAX_LEG_SLOTS) - 1u));
-    const float rl = __frcp_rn((float)max(n_leg_active, 1)), rb = __frcp_rn((float)max(n_base_active, 1));
+    const float rl = frcp((float)max(n_leg_active, 1)), rb = frcp((float)max(n_base_active, 1));
 
     // ---- joint position limits (URDF lower / upper, equal = none) as unilateral constraints on the joint rate, active
     // when the free motion would carry the joint past its stop within this step; W = response of the joint rate to a
@@ -409,11 +410,11 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             lmask |= 1u << j;
             LM(j, 0) = sgn;
             LM(j, 1) = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
-            LM(j, 2) = Wj > 1e-9f ? __frcp_rn(Wj) : 0.f;
+            LM(j, 2) = Wj > 1e-9f ? frcp(Wj) : 0.f;
             LM(j, 3) = 0.f;
         }
     }
-    const float rlim = __frcp_rn((float)max(__popc(lmask), 1));
+    const float rlim = frcp((float)max(__popc(lmask), 1));
 
     // ---- projected Jacobi sweeps (wave-uniform trip counts; waves without contacts or active limits skip them)
     if (__any((amask | lmask) != 0u)) {
@@ -445,7 +446,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                     vc2 += CF(si, 10) * (l1 - ol1);
                     float l2 = ol2 - relax * vc2 * CF(si, 11);
                     float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
-                    if (mag > lim) { float sc = lim * __frcp_rn(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
+                    if (mag > lim) { float sc = lim * frcp(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
                     V3 dl = (ln - oln) * nb + (l1 - ol1) * t1 + (l2 - ol2) * t2;
                     CF(si, 13) = ln; CF(si, 14) = l1; CF(si, 15) = l2;
                     Sv f = {cross(Pc, dl), dl};

@@ -11,7 +11,7 @@ import numpy as np
 from . import capi
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_DIR, "lib", "liblegged_hip.so")
+SO_PATH = os.environ.get("LG_HIP_LIB") or os.path.join(_DIR, "lib", "liblegged_hip.so")   # LG_HIP_LIB: A/B builds of the same tree
 _lib = None
 
 

@@ -8,7 +8,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "legged_gym_dev_amd", "lib", "liblegged_hip.so")
+SO = os.environ.get("LG_HIP_LIB") or os.path.join(ROOT, "legged_gym_dev_amd", "lib", "liblegged_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
