@@ -248,6 +248,9 @@ __device__ void resample_commands(const DevParams *P, int i, int slot0, int64_t 
 __device__ __forceinline__ float fnorm3(const float *f) { return sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]); }
 
 struct RewardCtx {
+    const float *js;    // the eight joint-summed terms of this env (k_post_step phase A1), JS_* below
+    float *air;         // feet_air_time / last_contacts rows of this env (LDS copies: the stateful feet_air_time term updates them)
+    uint8_t *lc;
     V3 blv, bav, pg;
     const float *cmd, *cf, *tau, *act, *lact, *lqd;
     const float *dof;   // interleaved q, qd
@@ -255,6 +258,7 @@ struct RewardCtx {
     bool reset, time_out;
 };
 
+enum { JS_TORQUES = 0, JS_DOF_VEL, JS_DOF_ACC, JS_ACTION_RATE, JS_DOF_POS_LIMITS, JS_DOF_VEL_LIMITS, JS_TORQUE_LIMITS, JS_STAND_STILL, JS_N };
 __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &x) {   // LR:918-1015, CA:43-46
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions, F = c.num_feet, H = c.num_height_points;
@@ -269,31 +273,17 @@ __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &
         float bh = s / (float)H;
         return (bh - c.base_height_target) * (bh - c.base_height_target);
     }
-    case LG_REW_TORQUES: for (int j = 0; j < A; ++j) s += x.tau[j] * x.tau[j]; return s;
-    case LG_REW_DOF_VEL: for (int j = 0; j < A; ++j) s += x.dof[2 * j + 1] * x.dof[2 * j + 1]; return s;
-    case LG_REW_DOF_ACC:
-        for (int j = 0; j < A; ++j) { float a = (x.lqd[j] - x.dof[2 * j + 1]) / c.dt; s += a * a; }
-        return s;
-    case LG_REW_ACTION_RATE:
-        for (int j = 0; j < A; ++j) { float a = x.lact[j] - x.act[j]; s += a * a; }
-        return s;
+    case LG_REW_TORQUES: return x.js[JS_TORQUES];
+    case LG_REW_DOF_VEL: return x.js[JS_DOF_VEL];
+    case LG_REW_DOF_ACC: return x.js[JS_DOF_ACC];
+    case LG_REW_ACTION_RATE: return x.js[JS_ACTION_RATE];
     case LG_REW_COLLISION:
         for (int b = 0; b < c.num_pen; ++b) s += fnorm3(x.cf + 3 * c.pen_idx[b]) > 0.1f ? 1.0f : 0.0f;
         return s;
     case LG_REW_TERMINATION: return (x.reset && !x.time_out) ? 1.0f : 0.0f;
-    case LG_REW_DOF_POS_LIMITS:
-        for (int j = 0; j < A; ++j) {
-            float q = x.dof[2 * j];
-            s += -fminf(q - c.dof_pos_limits[j][0], 0.0f) + fmaxf(q - c.dof_pos_limits[j][1], 0.0f);
-        }
-        return s;
-    case LG_REW_DOF_VEL_LIMITS:
-        for (int j = 0; j < A; ++j)
-            s += clampf(fabsf(x.dof[2 * j + 1]) - c.dof_vel_limits[j] * c.soft_dof_vel_limit, 0.0f, 1.0f);
-        return s;
-    case LG_REW_TORQUE_LIMITS:
-        for (int j = 0; j < A; ++j) s += fmaxf(fabsf(x.tau[j]) - c.torque_limits[j] * c.soft_torque_limit, 0.0f);
-        return s;
+    case LG_REW_DOF_POS_LIMITS: return x.js[JS_DOF_POS_LIMITS];
+    case LG_REW_DOF_VEL_LIMITS: return x.js[JS_DOF_VEL_LIMITS];
+    case LG_REW_TORQUE_LIMITS: return x.js[JS_TORQUE_LIMITS];
     case LG_REW_TRACKING_LIN_VEL: {
         float dx = x.cmd[0] - x.blv.x, dy = x.cmd[1] - x.blv.y;
         return expf(-(dx * dx + dy * dy) / c.tracking_sigma);
@@ -303,8 +293,8 @@ __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &
         return expf(-(d * d) / c.tracking_sigma);
     }
     case LG_REW_FEET_AIR_TIME: {
-        float *air = P->buf.feet_air_time + (size_t)i * F;
-        uint8_t *lc = P->buf.last_contacts + (size_t)i * F;
+        float *air = x.air;                                            // staged in LDS by the caller, written back after phase A
+        uint8_t *lc = x.lc;
         for (int f = 0; f < F; ++f) {
             bool contact = x.cf[3 * c.feet_idx[f] + 2] > 1.0f;
             bool filt = contact || lc[f];
@@ -328,9 +318,8 @@ __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &
         return any ? 1.0f : 0.0f;
     }
     case LG_REW_STAND_STILL: {
-        for (int j = 0; j < A; ++j) s += fabsf(x.dof[2 * j] - c.default_dof_pos[j]);
         float cn = sqrtf(x.cmd[0] * x.cmd[0] + x.cmd[1] * x.cmd[1]);
-        return s * (cn < 0.1f ? 1.0f : 0.0f);
+        return x.js[JS_STAND_STILL] * (cn < 0.1f ? 1.0f : 0.0f);
     }
     case LG_REW_FEET_CONTACT_FORCES:
         for (int f = 0; f < F; ++f) s += fmaxf(fnorm3(x.cf + 3 * c.feet_idx[f]) - c.max_contact_force, 0.0f);
@@ -572,34 +561,96 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
 
     // ---- phase H: height scan of the pre-reset pose (LR:356-357)
     if (c.measure_heights) {
-        for (int idx = tid; idx < nE * H; idx += LG_TILE_THREADS) {
-            const int e = env0 + idx / H, h = idx % H;
-            float v = 0.0f;
-            if (c.terrain_type == 1) v = height_sample(P, P->buf.root_states + (size_t)e * 13, h);
-            P->buf.measured_heights[(size_t)e * H + h] = v;
+        // four scan points per lane and trip: their 12 height-sample gathers are independent and in flight together (one lane
+        // per point and trip exposed three dependent-latency round trips per trip to a lone wave)
+        for (int idx0 = tid; idx0 < nE * H; idx0 += 4 * LG_TILE_THREADS) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(idx0 + u * LG_TILE_THREADS, nE * H - 1);
+                const int e = env0 + idx / H, h = idx % H;
+                v[u] = c.terrain_type == 1 ? height_sample(P, P->buf.root_states + (size_t)e * 13, h) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * LG_TILE_THREADS;
+                if (idx < nE * H) P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H] = v[u];
+            }
+        }
+    }
+    // contact forces and the feet state of the tile, staged once (coalesced) for the per-env lane of phase A
+    __shared__ float s_cf[TILE * LG_MAX_BODIES * 3];
+    __shared__ float s_air[TILE * LG_MAX_FEET];
+    __shared__ uint8_t s_lc[TILE * LG_MAX_FEET];
+    {
+        const int F = c.num_feet, nb = B * 3;
+        const float *gcf = P->buf.contact_forces + (size_t)env0 * nb;
+        for (int idx = tid; idx < nE * nb; idx += LG_TILE_THREADS) s_cf[(idx / nb) * (LG_MAX_BODIES * 3) + idx % nb] = gcf[idx];
+        for (int idx = tid; idx < nE * F; idx += LG_TILE_THREADS) {
+            s_air[(idx / F) * LG_MAX_FEET + idx % F] = P->buf.feet_air_time[(size_t)env0 * F + idx];
+            s_lc[(idx / F) * LG_MAX_FEET + idx % F] = P->buf.last_contacts[(size_t)env0 * F + idx];
         }
     }
     __syncthreads();
     STAMP(1);
 
-    // ---- phase A: one lane per env: LR:111-129
-    if (tid < nE) {
-        const int i = env0 + tid;
+    // ---- phase A (LR:111-129,139-145,189-206).  16 lanes per env (the workgroup is 16 envs x 16 lanes, one DPP row each):
+    //   A1  every joint-summed reward ingredient on a lane per joint, reduced over the row (a lone lane per env walked each
+    //       sum joint by joint, one exposed global-load latency per iteration);
+    //   A2  lane 0 of the row: frames, commands / trajectory generator, pushes, termination and the remaining terms; all
+    //       loads first, term values into LDS, stores last -- a store to a state buffer in the middle makes every later
+    //       load wait for it (the buffers may alias as far as the compiler knows);
+    //   A3  all lanes: episode sums (+ the logging sums of the envs that reset).
+    static_assert(TILE * 16 == LG_TILE_THREADS, "phase A: 16 lanes per environment");
+    __shared__ float s_tv[TILE][LG_NUM_TERMS];
+    __shared__ float s_js[TILE][JS_N];
+    __shared__ uint8_t s_rst[TILE];
+    const int e16 = tid >> 4, l16 = tid & 15;
+    {
+        const int i = env0 + min(e16, nE - 1);
+        float pj[JS_N];
+#pragma unroll
+        for (int k = 0; k < JS_N; ++k) pj[k] = 0.0f;
+        if (l16 < A) {
+            const size_t ij = (size_t)i * A + l16;
+            const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[ij];
+            const float tau = P->buf.torques[ij], act = P->buf.actions[ij], lact = P->buf.last_actions[ij], lqd = P->buf.last_dof_vel[ij];
+            const float q = st.x, qd = st.y, acc = (lqd - qd) / c.dt, da = lact - act;
+            pj[JS_TORQUES] = tau * tau;
+            pj[JS_DOF_VEL] = qd * qd;
+            pj[JS_DOF_ACC] = acc * acc;
+            pj[JS_ACTION_RATE] = da * da;
+            pj[JS_DOF_POS_LIMITS] = -fminf(q - c.dof_pos_limits[l16][0], 0.0f) + fmaxf(q - c.dof_pos_limits[l16][1], 0.0f);
+            pj[JS_DOF_VEL_LIMITS] = clampf(fabsf(qd) - c.dof_vel_limits[l16] * c.soft_dof_vel_limit, 0.0f, 1.0f);
+            pj[JS_TORQUE_LIMITS] = fmaxf(fabsf(tau) - c.torque_limits[l16] * c.soft_torque_limit, 0.0f);
+            pj[JS_STAND_STILL] = fabsf(q - c.default_dof_pos[l16]);
+        }
+#pragma unroll
+        for (int k = 0; k < JS_N; ++k) pj[k] = row16_sum(pj[k]);
+        if (l16 == 0) {
+#pragma unroll
+            for (int k = 0; k < JS_N; ++k) s_js[e16][k] = pj[k];
+            s_rst[e16] = 0;
+        }
+    }
+    if (l16 == 0 && e16 < nE) {
+        const int i = env0 + e16;
         float *r = P->buf.root_states + (size_t)i * 13;
         float *cmd = P->buf.commands + (size_t)i * 4;
-        const float *cf = P->buf.contact_forces + (size_t)i * B * 3;
+        const float *cf = s_cf + e16 * (LG_MAX_BODIES * 3);
         const int64_t ep = P->buf.episode_length[i] + 1;                   // LR:114
-        P->buf.episode_length[i] = ep;
         RewardCtx x;
+        x.js = s_js[e16];
+        x.air = s_air + e16 * LG_MAX_FEET;
+        x.lc = s_lc + e16 * LG_MAX_FEET;
         x.blv = quat_rotate_inverse(r + 3, V3{r[7], r[8], r[9]});        // LR:118-121
         x.bav = quat_rotate_inverse(r + 3, V3{r[10], r[11], r[12]});
         x.pg = quat_rotate_inverse(r + 3, V3{0.0f, 0.0f, -1.0f});
-        float *o3 = P->buf.base_lin_vel + 3 * (size_t)i;
-        o3[0] = x.blv.x; o3[1] = x.blv.y; o3[2] = x.blv.z;
-        o3 = P->buf.base_ang_vel + 3 * (size_t)i;
-        o3[0] = x.bav.x; o3[1] = x.bav.y; o3[2] = x.bav.z;
-        o3 = P->buf.projected_gravity + 3 * (size_t)i;
-        o3[0] = x.pg.x; o3[1] = x.pg.y; o3[2] = x.pg.z;
+        bool rst = false;                                                   // LR:139-145 (contact forces do not change below)
+        for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
+        const bool flt = P->fault[i] != 0;                                  // physics fault guard (lg_physics.h)
+        const bool to = ep > c.max_episode_length;
+        rst = rst || flt || to;
         if (c.traj.enabled) tg_callback_step(P, i, counter, inject);       // LT:405-417
         else if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject);   // LR:348-350
         if (c.heading_command && !c.traj.enabled) {                         // LR:351-354, math.py:45-48
@@ -624,13 +675,6 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
             r[7] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH, counter, inject) + (-c.max_push_vel);
             r[8] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH + 1, counter, inject) + (-c.max_push_vel);
         }
-        bool rst = false;                                                   // LR:139-145
-        for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
-        if (P->fault[i]) { rst = true; P->fault[i] = 0; atomicAdd(&s_flt, 1); }   // physics fault guard (lg_physics.h)
-        const bool to = ep > c.max_episode_length;
-        rst = rst || to;
-        P->buf.time_out[i] = to;
-        P->buf.reset[i] = rst;
         x.cmd = cmd; x.cf = cf; x.root_z = r[2]; x.reset = rst; x.time_out = to;
         x.dof = P->buf.dof_state + (size_t)i * A * 2;
         x.tau = P->buf.torques + (size_t)i * A; x.act = P->buf.actions + (size_t)i * A;
@@ -642,23 +686,43 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
             if (k < LG_NUM_REWARDS) v = reward_term(P, i, k, x) * c.rew_scale[k];
             else v = xterm_value(P, i, c.xterms[k - LG_NUM_REWARDS], x) * c.xterms[k - LG_NUM_REWARDS].scale;
             rew += v;
-            P->buf.episode_sums[(size_t)k * N + i] += v;
+            s_tv[e16][k] = v;
         }
         if (c.only_positive_rewards) rew = fmaxf(rew, 0.0f);
         if (c.rew_scale[LG_REW_TERMINATION] != 0.0f) {
             float v = reward_term(P, i, LG_REW_TERMINATION, x) * c.rew_scale[LG_REW_TERMINATION];
             rew += v;
-            P->buf.episode_sums[(size_t)LG_REW_TERMINATION * N + i] += v;
+            s_tv[e16][LG_REW_TERMINATION] = v;
         }
+        // ---- stores of this phase
+        P->buf.episode_length[i] = ep;
+        float *o3 = P->buf.base_lin_vel + 3 * (size_t)i;
+        o3[0] = x.blv.x; o3[1] = x.blv.y; o3[2] = x.blv.z;
+        o3 = P->buf.base_ang_vel + 3 * (size_t)i;
+        o3[0] = x.bav.x; o3[1] = x.bav.y; o3[2] = x.bav.z;
+        o3 = P->buf.projected_gravity + 3 * (size_t)i;
+        o3[0] = x.pg.x; o3[1] = x.pg.y; o3[2] = x.pg.z;
+        P->buf.time_out[i] = to;
+        P->buf.reset[i] = rst;
         P->buf.rew[i] = rew;
-        if (rst) {                                                          // LR:147-187
-            s_list[atomicAdd(&s_cnt, 1)] = i;
-            for (int k = 0; k < LG_NUM_TERMS; ++k)
-                if (term_scale(c, k) != 0.0f) {
-                    atomicAdd(&s_acc[k], P->buf.episode_sums[(size_t)k * N + i]);
-                    P->buf.episode_sums[(size_t)k * N + i] = 0.0f;
-                }
+        if (flt) { P->fault[i] = 0; atomicAdd(&s_flt, 1); }
+        if (rst) { s_list[atomicAdd(&s_cnt, 1)] = i; s_rst[e16] = 1; }    // LR:147-187
+    }
+    __syncthreads();
+    if (c.rew_scale[LG_REW_FEET_AIR_TIME] != 0.0f)                        // the term's state, back to HBM (a reset below clears its rows)
+        for (int idx = tid; idx < nE * c.num_feet; idx += LG_TILE_THREADS) {
+            P->buf.feet_air_time[(size_t)env0 * c.num_feet + idx] = s_air[(idx / c.num_feet) * LG_MAX_FEET + idx % c.num_feet];
+            P->buf.last_contacts[(size_t)env0 * c.num_feet + idx] = s_lc[(idx / c.num_feet) * LG_MAX_FEET + idx % c.num_feet];
         }
+    // A3: episode_sums += term value (LR:196-197,205); the sums of resetting envs go to the logging accumulators and are cleared
+    for (int idx = tid; idx < nE * (c.num_terms + 1); idx += LG_TILE_THREADS) {
+        const int e2 = idx / (c.num_terms + 1), o = idx % (c.num_terms + 1);
+        if (o == c.num_terms && c.rew_scale[LG_REW_TERMINATION] == 0.0f) continue;
+        const int k = o < c.num_terms ? c.term_order[o] : LG_REW_TERMINATION;
+        float *es = P->buf.episode_sums + (size_t)k * N + env0 + e2;
+        const float v = *es + s_tv[e2][k];
+        if (s_rst[e2]) { atomicAdd(&s_acc[k], v); *es = 0.0f; }
+        else *es = v;
     }
     __syncthreads();
     STAMP(2);
@@ -673,24 +737,50 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
     // ---- phase O: observations (LR:208-226), clip (LR:100-103), bookkeeping (LR:132-134)
     const int ob = c.traj.enabled ? 9 + 2 * c.traj.N : 12;              // first joint entry: after commands[:3] | the trajectory block
     const int s_noise = c.traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A);
-    for (int idx = tid; idx < nE * O; idx += LG_TILE_THREADS) {
-        const int i = env0 + idx / O, k = idx % O;
-        const float *r = P->buf.root_states + (size_t)i * 13;
-        float v;
-        if (k < 3) v = P->buf.base_lin_vel[3 * (size_t)i + k] * c.obs_scale_lin_vel;
-        else if (k < 6) v = P->buf.base_ang_vel[3 * (size_t)i + k - 3] * c.obs_scale_ang_vel;
-        else if (k < 9) v = P->buf.projected_gravity[3 * (size_t)i + k - 6];
-        else if (k < ob) {
-            if (c.traj.enabled) v = (P->buf.trajectory[(size_t)i * 2 * c.traj.N + (k - 9)] - r[(k - 9) & 1]) * c.traj.obs_scale[(k - 9) & 1];   // LT:280-288
-            else v = P->buf.commands[(size_t)i * 4 + k - 9] * (k == 11 ? c.obs_scale_ang_vel : c.obs_scale_lin_vel);
-        }
-        else if (k < ob + A) v = (P->buf.dof_state[((size_t)i * A + k - ob) * 2] - c.default_dof_pos[k - ob]) * c.obs_scale_dof_pos;
-        else if (k < ob + 2 * A) v = P->buf.dof_state[((size_t)i * A + k - ob - A) * 2 + 1] * c.obs_scale_dof_vel;
-        else if (k < ob + 3 * A) v = P->buf.actions[(size_t)i * A + k - ob - 2 * A];
-        else v = clampf(r[2] - 0.5f - P->buf.measured_heights[(size_t)i * H + k - ob - 3 * A], -1.0f, 1.0f) * c.obs_scale_height;
+    // Segment by segment (frame block | joint positions | joint rates | actions | heights), four entries per lane and trip with
+    // their operand loads issued together: one generic loop over all entries took a different branch -- and exposed one more
+    // global-load latency to the lone wave -- for every kind of entry its 64 lanes happened to hold.
+    auto emit = [&](int i, int k, float v) {
         if (c.add_noise) v += (2.0f * uni(P, i, s_noise + k, counter, inject) - 1.0f) * P->noise_vec[k];
         P->buf.obs[(size_t)i * O + k] = clampf(v, -c.clip_obs, c.clip_obs);
+    };
+    for (int idx = tid; idx < nE * ob; idx += LG_TILE_THREADS) {           // lin vel, ang vel, gravity, commands | trajectory
+        const int i = env0 + idx / ob, k = idx % ob;
+        const float *r = P->buf.root_states + (size_t)i * 13;
+        float v;
+        if (k < 9) {
+            const float *src = k < 3 ? P->buf.base_lin_vel : k < 6 ? P->buf.base_ang_vel : P->buf.projected_gravity;
+            v = src[3 * (size_t)i + k % 3] * (k < 3 ? c.obs_scale_lin_vel : k < 6 ? c.obs_scale_ang_vel : 1.0f);
+        } else if (c.traj.enabled) {
+            v = (P->buf.trajectory[(size_t)i * 2 * c.traj.N + (k - 9)] - r[(k - 9) & 1]) * c.traj.obs_scale[(k - 9) & 1];   // LT:280-288
+        } else {
+            v = P->buf.commands[(size_t)i * 4 + k - 9] * (k == 11 ? c.obs_scale_ang_vel : c.obs_scale_lin_vel);
+        }
+        emit(i, k, v);
     }
+    for (int idx = tid; idx < nE * A; idx += LG_TILE_THREADS) {            // joint positions, rates, actions: one lane per (env, joint)
+        const int i = env0 + idx / A, j = idx % A;
+        const float2 st = reinterpret_cast<const float2 *>(P->buf.dof_state)[(size_t)i * A + j];
+        const float act = P->buf.actions[(size_t)i * A + j];
+        emit(i, ob + j, (st.x - c.default_dof_pos[j]) * c.obs_scale_dof_pos);
+        emit(i, ob + A + j, st.y * c.obs_scale_dof_vel);
+        emit(i, ob + 2 * A + j, act);
+    }
+    if (c.measure_heights)
+        for (int idx0 = tid; idx0 < nE * H; idx0 += 4 * LG_TILE_THREADS) { // height entries, four in flight
+            float hv[4], rz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(idx0 + u * LG_TILE_THREADS, nE * H - 1);
+                hv[u] = P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H];
+                rz[u] = P->buf.root_states[(size_t)(env0 + idx / H) * 13 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = idx0 + u * LG_TILE_THREADS;
+                if (idx < nE * H) emit(env0 + idx / H, ob + 3 * A + idx % H, clampf(rz[u] - 0.5f - hv[u], -1.0f, 1.0f) * c.obs_scale_height);
+            }
+        }
     for (int idx = tid; idx < nE * A; idx += LG_TILE_THREADS) {
         const size_t ij = (size_t)env0 * A + idx;
         P->buf.last_actions[ij] = P->buf.actions[ij];

@@ -125,8 +125,17 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ float quad_xor1(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
 }
+// sum over the 16 lanes of a DPP row, result in every lane: quad butterflies, then the two mirror permutes
+__device__ __forceinline__ float row16_sum(float x);
 __device__ __forceinline__ float quad_xor2(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += quad_xor1(x);
+    x += quad_xor2(x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141 /*row_half_mirror*/, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140 /*row_mirror*/, 0xF, 0xF, true));
+    return x;
 }
 
 // ------------------------------------------------------------------ Philox4x32-10
@@ -139,6 +148,13 @@ __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, uint32_t c[
         c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
+}
+// the four uniforms of slots 4 * block .. 4 * block + 3 from ONE Philox evaluation (each is what philox_uniform returns for its slot)
+__device__ __forceinline__ void philox_uniform4(uint64_t seed, uint32_t env, uint64_t step, uint32_t block, float out[4]) {
+    uint32_t c[4] = {env, (uint32_t)step, block, (uint32_t)(step >> 32)};
+    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (float)(c[r] >> 8) * (1.0f / 16777216.0f);
 }
 __device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t env, uint64_t step, uint32_t slot) {
     uint32_t c[4] = {env, (uint32_t)step, slot >> 2, (uint32_t)(step >> 32)};
