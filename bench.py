@@ -62,7 +62,7 @@ def make_runner(num_envs, hidden, device, rank, world):
 
 
 def time_iterations(runner, steps, warmup, world):
-    ar = runner._all_reduce if world > 1 else None
+    ar = runner._grad_reduce
     for _ in range(warmup):
         runner.rollout()
         runner.ppo.update(ar)
@@ -297,7 +297,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    if world > 1:
+    if world > 1:        # the process group also serves the barrier / MAX of the timing contract when LG_COMM=native reduces the gradients
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device(device))
         else:

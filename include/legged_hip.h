@@ -321,6 +321,27 @@ int lg_ppo_end_update(lg_ppo *p);                  /* finalise mean losses, clea
 /* actor mean only (act_inference) for play/eval */
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows);
 
+/* ------------------------------------------------------------------ collectives (nothing in the reference to
+ * replace -- it has no multi-GPU code; this is the exchange step the env-sharded learner needs).  One process per GPU; rank r
+ * owns envs [r N/G, (r+1) N/G).  RCCL over xGMI, resolved from the librccl.so already in the process (no link dependency).
+ * The Python runner may use torch.distributed instead (same RCCL underneath); these entries are for hosts without it, and for
+ * the reduction overlapped with the backward pass, which needs the learner's own streams. */
+#define LG_COMM_ID_BYTES 128
+typedef struct lg_comm lg_comm;
+int lg_comm_get_unique_id(void *id_out /* LG_COMM_ID_BYTES, host */);   /* rank 0; the host carries the bytes to the other ranks */
+int lg_comm_init(int rank, int nranks, const void *id, lg_comm **out);  /* collective over all ranks; device = hipGetDevice() */
+int lg_comm_destroy(lg_comm *c);
+int lg_comm_rank(lg_comm *c);
+int lg_comm_size(lg_comm *c);
+int lg_comm_allreduce_sum(lg_comm *c, float *buf /* device, in place */, int64_t n, void *stream);
+int lg_comm_broadcast(lg_comm *c, float *buf, int64_t n, int root, void *stream);
+/* The learner's three exchanges.  lg_ppo_set_comm(p, c) makes lg_ppo_minibatch_backward reduce the gradients itself, layer by
+ * layer as their weight-gradient GEMMs finish (the head's bucket carries std and the KL sum), on the communicator's stream
+ * beside the remaining backward GEMMs; lg_ppo_minibatch_step then waits for the last bucket.  c = NULL switches it off. */
+int lg_ppo_set_comm(lg_ppo *p, lg_comm *c);
+int lg_ppo_allreduce_adv_moments(lg_ppo *p, lg_comm *c);   /* between lg_ppo_compute_returns and lg_ppo_normalize_advantages */
+int lg_ppo_broadcast_params(lg_ppo *p, lg_comm *c, int root);   /* identical initial policy on every rank */
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,3 +197,5 @@ PPO_SYMBOLS = ["ppo_create", "ppo_destroy", "ppo_get_buffers", "ppo_set_stream",
                "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_step",
                "ppo_end_update", "ppo_act_inference"]
 HIP_ONLY_SYMBOLS = ["version", "set_stream"]
+COMM_SYMBOLS = ["comm_get_unique_id", "comm_init", "comm_destroy", "comm_rank", "comm_size", "comm_allreduce_sum", "comm_broadcast",
+                "ppo_set_comm", "ppo_allreduce_adv_moments", "ppo_broadcast_params"]

@@ -38,7 +38,19 @@ struct Net {
     float *dz[LG_PPO_MAX_LAYERS + 1];        // gradient wrt act[l] pre-activation
 };
 
+struct lg_comm;
+extern "C" {
+hipStream_t lg_comm_stream_(lg_comm *c);
+hipEvent_t lg_comm_event_(lg_comm *c);
+int lg_comm_group_allreduce_(lg_comm *c, float *const *bufs, const int64_t *counts, int n, hipStream_t s);
+int lg_comm_allreduce_sum(lg_comm *c, float *buf, int64_t n, void *stream);
+int lg_comm_broadcast(lg_comm *c, float *buf, int64_t n, int root, void *stream);
+}
+
 struct lg_ppo {
+    lg_comm *comm;                           // when set: gradients are reduced per layer inside the backward pass
+    hipEvent_t ev_bucket;                    // a layer's weight gradients are complete on the side stream
+    int comm_rc;
     lg_ppo_cfg cfg;
     PpoDev dev;
     Net net[2];                              // 0 actor, 1 critic
@@ -99,6 +111,30 @@ static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int ma
     }
 }
 
+// Gradient bucket of layer l (both nets: W_l and b_l are adjacent in the flat buffer), all-reduced on the communicator's stream
+// as soon as the layer's weight-gradient GEMM is done.  b_l was summed by the input-gradient GEMM of layer l+1 (or by the loss
+// kernel for the head), which the weight-gradient GEMM of layer l already waited for.  The head's bucket also carries std and
+// the [KL sum | pad] tail.  The collectives of one bucket are one RCCL group.
+static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
+    float *bufs[4];
+    int64_t counts[4];
+    int n = 0;
+    for (int z = 0; z < 2; ++z) {
+        Net &net = p->net[z];
+        bufs[n] = p->dev.grads + net.w_off[l];
+        counts[n++] = (int64_t)net.dims[l + 1] * net.dims[l] + net.dims[l + 1];
+    }
+    if (l == p->net[0].nl - 1) {
+        bufs[n] = p->dev.grads + p->dev.off_std; counts[n++] = p->cfg.num_actions;
+        bufs[n] = p->dev.grads + p->dev.num_params; counts[n++] = 2;
+    }
+    hipStream_t cs = lg_comm_stream_(p->comm);
+    (void)hipEventRecord(p->ev_bucket, ready_on);
+    (void)hipStreamWaitEvent(cs, p->ev_bucket, 0);
+    const int rc = lg_comm_group_allreduce_(p->comm, bufs, counts, n, cs);
+    if (rc && !p->comm_rc) p->comm_rc = rc;
+}
+
 // backward of both nets on M rows given dz[nl] (head output gradients) already filled
 static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int skip_head = 0) {
     const float *in[2] = {in0, in1};
@@ -126,13 +162,13 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         int max_splits = M / 256 > 0 ? M / 256 : 1;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
+        hipStream_t dw_stream = p->overlap ? p->side : p->stream;
         if (p->overlap) {                            // dz[l+1] is complete on the main stream at this point
             (void)hipEventRecord(p->ev_dz, p->stream);
             (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
-            ppok_gemm_dw(&g, 2, splits, p->side);
-        } else {
-            ppok_gemm_dw(&g, 2, splits, p->stream);
         }
+        ppok_gemm_dw(&g, 2, splits, dw_stream);
+        if (p->comm) reduce_layer_bucket(p, l, dw_stream);
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * act'(act[l]); db_{l-1} = colsum(dz[l])
             memset(&g, 0, sizeof(g));
             for (int z = 0; z < 2; ++z) {
@@ -154,6 +190,10 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         (void)hipEventRecord(p->ev_side, p->side);
         (void)hipStreamWaitEvent(p->stream, p->ev_side, 0);
     }
+    if (p->comm) {                                   // ... and every reduced bucket
+        (void)hipEventRecord(lg_comm_event_(p->comm), lg_comm_stream_(p->comm));
+        (void)hipStreamWaitEvent(p->stream, lg_comm_event_(p->comm), 0);
+    }
 }
 
 extern "C" {
@@ -163,6 +203,7 @@ int lg_ppo_destroy(lg_ppo *p) {
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
     if (p->ev_dz) (void)hipEventDestroy(p->ev_dz);
     if (p->ev_side) (void)hipEventDestroy(p->ev_side);
+    if (p->ev_bucket) (void)hipEventDestroy(p->ev_bucket);
     for (void *q : p->allocs) (void)hipFree(q);
     delete p;
     return 0;
@@ -191,10 +232,12 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->overlap = getenv("LG_PPO_OVERLAP") ? atoi(getenv("LG_PPO_OVERLAP")) : 1;
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_bucket, hipEventDisableTiming) != hipSuccess) {
         lg_set_error("stream/event creation failed"); delete p; return -100;
     }
     p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0;
+    p->comm = nullptr; p->comm_rc = 0;
     p->perm_count = 0;
     const int R = (int)((long)N * T / cfg->num_mini_batches);
     p->Mmax = R > N ? R : N;
@@ -392,7 +435,9 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     } else {
         ppok_loss(&d, na.act[na.nl], nc.act[nc.nl], na.dz[na.nl], nc.dz[nc.nl], p->stream);
     }
+    if (fuse && p->comm) reduce_layer_bucket(p, nl - 1, p->stream);   // the fused head produced the head layer's gradients itself
     backward(p, R, d.mb_obs, d.mb_critic_obs, fuse ? 1 : 0);
+    if (p->comm_rc) { const int rc = p->comm_rc; p->comm_rc = 0; return rc; }
     return launch_ok();
 }
 
@@ -404,6 +449,12 @@ int lg_ppo_minibatch_step(lg_ppo *p) {
 }
 
 int lg_ppo_end_update(lg_ppo *p) { p->step = 0; return 0; }
+
+int lg_ppo_set_comm(lg_ppo *p, lg_comm *c) { p->comm = c; return 0; }
+int lg_ppo_allreduce_adv_moments(lg_ppo *p, lg_comm *c) { return lg_comm_allreduce_sum(c, p->dev.adv_partial, 4, p->stream); }
+int lg_ppo_broadcast_params(lg_ppo *p, lg_comm *c, int root) {
+    return lg_comm_broadcast(c, p->dev.params, p->dev.num_params + 2, root, p->stream);
+}
 
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows) {
     if (rows > p->Mmax) { lg_set_error("too many rows for act_inference"); return -11; }

@@ -1,0 +1,112 @@
+"""The learner's collectives.
+
+``TorchDistComm``  -- over an initialised ``torch.distributed`` process group (backend "nccl" is RCCL on ROCm; "gloo" for
+                      rehearsals on one GPU).  One all-reduce of the whole [gradients | KL] buffer per optimiser step.
+``NativeComm``     -- RCCL through the library's own C-ABI (lg_comm_*, include/legged_hip.h): no process group; the unique id
+                      travels through a ``torch.distributed.TCPStore`` (a plain key-value store) at MASTER_ADDR:MASTER_PORT.
+                      The gradient reduction then happens INSIDE lg_ppo_minibatch_backward, layer by layer on a side stream as
+                      each layer's weight-gradient GEMM finishes, overlapped with the rest of the backward pass.
+Select with LG_COMM=native|torch (default torch) when launching one process per GPU (torchrun, bench.py --gpus N, train.py).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from legged_gym_dev_amd.lib import LeggedHipError, load
+
+ID_BYTES = 128
+
+
+class TorchDistComm:
+    overlapped = False
+
+    def __init__(self):
+        self.rank, self.world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
+
+    def all_reduce(self, t):
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+
+    def broadcast(self, t, src=0):
+        torch.distributed.broadcast(t, src=src)
+
+    def attach(self, ppo):
+        pass
+
+    def close(self):
+        pass
+
+
+class NativeComm:
+    overlapped = True                       # gradients are reduced by lg_ppo_minibatch_backward itself
+
+    def __init__(self, rank, world_size, unique_id=None, store=None):
+        self.lib = load()
+        self.rank, self.world_size = int(rank), int(world_size)
+        vp = C.c_void_p
+        self.lib.lg_comm_get_unique_id.argtypes = [vp]
+        self.lib.lg_comm_init.argtypes = [C.c_int, C.c_int, vp, C.POINTER(vp)]
+        self.lib.lg_comm_destroy.argtypes = [vp]
+        self.lib.lg_comm_allreduce_sum.argtypes = [vp, vp, C.c_int64, vp]
+        self.lib.lg_comm_broadcast.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
+        self.lib.lg_ppo_set_comm.argtypes = [vp, vp]
+        if unique_id is None:
+            unique_id = self._exchange_id(store)
+        self._id = (C.c_char * ID_BYTES).from_buffer_copy(unique_id)
+        self.ctx = vp()
+        self._chk(self.lib.lg_comm_init(self.rank, self.world_size, self._id, C.byref(self.ctx)), "lg_comm_init")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise LeggedHipError(f"{what} failed ({rc}): {self.lib.lg_last_error().decode()}")
+
+    def new_unique_id(self):
+        buf = (C.c_char * ID_BYTES)()
+        self._chk(self.lib.lg_comm_get_unique_id(buf), "lg_comm_get_unique_id")
+        return bytes(buf)
+
+    def _exchange_id(self, store):
+        if self.world_size == 1:
+            return self.new_unique_id()
+        if store is None:
+            store = torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]) + 1,
+                                               self.world_size, is_master=self.rank == 0)
+        if self.rank == 0:
+            uid = self.new_unique_id()
+            store.set("lg_comm_id", uid)
+            return uid
+        return bytes(store.get("lg_comm_id"))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_reduce(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self._chk(self.lib.lg_comm_allreduce_sum(self.ctx, C.c_void_p(t.data_ptr()), t.numel(), self._stream()), "lg_comm_allreduce_sum")
+
+    def broadcast(self, t, src=0):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self._chk(self.lib.lg_comm_broadcast(self.ctx, C.c_void_p(t.data_ptr()), t.numel(), int(src), self._stream()), "lg_comm_broadcast")
+
+    def attach(self, ppo):
+        """From now on ppo's minibatch_backward reduces its own gradients (per-layer buckets, overlapped)."""
+        self._chk(self.lib.lg_ppo_set_comm(ppo.ctx, self.ctx), "lg_ppo_set_comm")
+        self._ppo = ppo
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            if getattr(self, "_ppo", None) is not None and self._ppo.ctx:
+                self.lib.lg_ppo_set_comm(self._ppo.ctx, None)
+            torch.cuda.synchronize()
+            self.lib.lg_comm_destroy(self.ctx)
+            self.ctx = None
+
+
+def default_comm():
+    """The communicator of a process launched as one rank per GPU, or None for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("LG_COMM", "torch") == "native" and world > 1:
+        return NativeComm(int(os.environ["RANK"]), world)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return TorchDistComm()
+    return None

@@ -15,6 +15,7 @@ from collections import deque
 import torch
 
 from legged_gym_dev_amd.capi import NUM_TERMS as _NUM_TERMS
+from .comm import TorchDistComm, default_comm  # noqa: F401  (TorchDistComm re-exported)
 from .ppo import HipPPO
 
 
@@ -68,20 +69,6 @@ class _Alg:
         return self.ppo.learning_rate
 
 
-class TorchDistComm:
-    """The collective of the multi-GPU path as the runner sees it: rank, world_size, all_reduce(SUM), broadcast.
-    Default implementation over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" for rehearsals)."""
-
-    def __init__(self):
-        self.rank, self.world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
-
-    def all_reduce(self, t):
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-
-    def broadcast(self, t, src=0):
-        torch.distributed.broadcast(t, src=src)
-
-
 class OnPolicyRunner:
     def __init__(self, env, train_cfg, log_dir=None, device="cuda:0", wandb_callback=None, comm=None):
         self.cfg = train_cfg["runner"]
@@ -89,8 +76,8 @@ class OnPolicyRunner:
         self.device = str(device).replace("hip", "cuda")
         self.env = env
         self.wandb_callback = wandb_callback
-        if comm is None and torch.distributed.is_available() and torch.distributed.is_initialized():
-            comm = TorchDistComm()
+        if comm is None:
+            comm = default_comm()
         self.comm = comm if comm is not None and comm.world_size > 1 else None
         self.world_size = self.comm.world_size if self.comm else 1
         self.rank = self.comm.rank if self.comm else 0
@@ -111,6 +98,8 @@ class OnPolicyRunner:
         if self.comm:                                 # identical initial policy on every rank
             torch.cuda.synchronize()
             self.comm.broadcast(self.ppo.t["params"], src=0)
+            if hasattr(self.comm, "attach"):
+                self.comm.attach(self.ppo)            # NativeComm: gradients reduced inside the backward pass from here on
         self.log_dir = log_dir
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.rewbuffer, self.lenbuffer = deque(maxlen=100), deque(maxlen=100)
@@ -119,6 +108,13 @@ class OnPolicyRunner:
 
     def _all_reduce(self, t):
         self.comm.all_reduce(t)
+
+    @property
+    def _grad_reduce(self):
+        """What ppo.update calls between backward and step: nothing when the communicator reduces inside the backward pass."""
+        if self.world_size == 1 or getattr(self.comm, "overlapped", False):
+            return None
+        return self._all_reduce
 
     # ------------------------------------------------------------------
     def rollout(self):
@@ -144,7 +140,7 @@ class OnPolicyRunner:
             stop = time.time()
             collection_time = stop - start
             start = stop
-            mean_value_loss, mean_surrogate_loss = ppo.update(self._all_reduce if self.world_size > 1 else None)
+            mean_value_loss, mean_surrogate_loss = ppo.update(self._grad_reduce)
             torch.cuda.synchronize()
             learn_time = time.time() - start
             self._log(it, tot_iter, collection_time, learn_time, float(mean_value_loss), float(mean_surrogate_loss))

@@ -413,3 +413,42 @@ def test_fewer_envs_than_action_dims():
         assert np.isfinite(st["kl"]) and st["lr"] > 1e-5 * 1.01 and bool(torch.isfinite(hip.t["params"]).all())
     finally:
         hip.close()
+
+
+def test_native_rccl_comm_single_rank():
+    """lg_comm_* (RCCL resolved from the process's librccl.so) with one rank -- what a one-GPU box can execute: unique id,
+    communicator, in-place all-reduce and broadcast on the caller's stream, and the learner's overlapped gradient reduction
+    (lg_ppo_set_comm: per-layer buckets all-reduced on the communicator's stream while the backward GEMMs run).  With one rank
+    every collective is the identity, so an update with the communicator attached must match one without it (tolerance: the
+    float atomics of the gradient kernels, as in test_two_rank_update_equals_single_process_update)."""
+    from legged_gym_dev_amd.rl.comm import NativeComm
+    comm = NativeComm(0, 1)
+    try:
+        x = torch.arange(1000, dtype=torch.float32, device="cuda")
+        comm.all_reduce(x)
+        comm.broadcast(x, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32))
+        assert comm.lib.lg_comm_rank(comm.ctx) == 0 and comm.lib.lg_comm_size(comm.ctx) == 1
+        N, O, A, T = 512, 48, 12, 8
+        outs = []
+        for attach in (False, True):
+            hip, ac, _ = _make(N, O, A, T, alg=dict(ALG, num_learning_epochs=2))
+            try:
+                g = torch.Generator(device="cuda").manual_seed(4)
+                _fill_rollout(hip, ac, T, N, O, A, g)
+                hip.compute_returns(torch.randn(N, O, device="cuda", generator=g))
+                if attach:
+                    comm.attach(hip)
+                hip.update()
+                torch.cuda.synchronize()
+                outs.append(hip.t["params"][: hip.num_params].clone())
+                assert bool(torch.isfinite(outs[-1]).all())
+                if attach:
+                    comm.lib.lg_ppo_set_comm(hip.ctx, None)
+            finally:
+                hip.close()
+        rel = float((outs[0] - outs[1]).norm() / outs[0].norm())
+        assert rel < 2e-4, rel
+    finally:
+        comm.close()
