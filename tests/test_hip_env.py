@@ -82,8 +82,21 @@ def test_physics_substep_matches_oracle(name, z0, oracle_built):
             cf_h, cf_o = hip.get("contact_forces"), ora.get("contact_forces")
             n_contact += int((np.abs(cf_o).sum(-1) > 0).sum())
             np.testing.assert_allclose(hip.get("root_states"), ora.get("root_states"), rtol=2e-4, atol=2e-4)
-            # joint velocities of the 0.15 kg Cassie toe links see accelerations > 1e3 rad/s^2: 2e-3
-            np.testing.assert_allclose(hip.get("dof_state"), ora.get("dof_state"), rtol=2e-3, atol=2e-3)
+            # Joint state: 2e-4 like the root.  What may leave that band -- asserted as stated -- is a joint RATE of an
+            # environment that is in ground contact during this substep (the projected-Jacobi sweeps clamp impulses to the
+            # friction cone; a lane-order or 1-ulp reciprocal difference that lands a tangential impulse on the other side of
+            # the clamp moves the rates of that leg by ~1e-3 rad/s): never a position, never an env in free flight, never
+            # beyond 2e-3, fewer than 0.1 % of the entries.  tools/diag_physics_band.py lists them (14 of 331 776 rates over
+            # three seeds x six robots: all rates, all in contact, largest 1.8e-3).
+            dh, do = hip.get("dof_state").astype(np.float64), ora.get("dof_state").astype(np.float64)
+            err = np.abs(dh - do)
+            band = err > 2e-4 + 2e-4 * np.abs(do)
+            assert not band[..., 0].any(), f"step {step}: joint positions outside 2e-4"
+            out = band[..., 1]
+            in_contact = np.abs(cf_o).reshape(n, -1).sum(1) > 1.0
+            assert out.mean() < 1e-3, int(out.sum())
+            assert in_contact[np.nonzero(out)[0]].all(), "a joint rate of an env without ground contact left the 2e-4 band"
+            assert (err[..., 1] <= 2e-3 + 2e-3 * np.abs(do[..., 1])).all(), err[..., 1].max()
             np.testing.assert_allclose(cf_h, cf_o, rtol=2e-3, atol=0.5)
             # re-synchronise so fp32 drift does not accumulate across steps (chaotic contacts)
             hip.set("root_states", ora.get("root_states"))

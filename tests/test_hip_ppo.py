@@ -124,6 +124,7 @@ def test_returns_and_gradients_match_torch():
         rel = float((got - ref).norm() / ref.norm())
         assert rel < 2e-4, rel
         torch.testing.assert_close(hip.t["grads"][hip.num_params] / R, kl, rtol=1e-3, atol=1e-6)
+        g_got, g_ref = got.clone(), ref.clone()            # the step below clears the buffer `got` views
         # ---- optimizer step vs clip_grad_norm_ + Adam with the KL-adaptive learning rate
         hip._call("minibatch_step")
         kl_f = float(kl)
@@ -136,12 +137,19 @@ def test_returns_and_gradients_match_torch():
         torch.nn.utils.clip_grad_norm_(ac.parameters(), 1.0)
         algo.optimizer.step()
         assert abs(hip.learning_rate - algo.learning_rate) < 1e-9
-        # Adam's first steps move every weight by ~lr * sign(g): weights whose gradient is at the
-        # fp32 noise floor may step the other way, so allow <0.05 % outliers bounded by 2 lr.
+        # Adam's first steps are lr * g / (|g| + eps) ~ lr * sign(g) per weight, whatever the gradient's size: a weight whose
+        # gradient is comparable to the GEMMs' fp32 summation noise can step a different amount (up to the other way) in the
+        # two implementations.  Asserted as stated: every parameter outside the band (2e-6 + 1e-4 |p|) has a gradient whose
+        # HIP-vs-autograd difference is at least 2 % of the gradient itself (or a gradient below 1e-6 of the largest), there
+        # are < 0.05 % of them, and none is off by more than the two sign steps taken so far.
         got_p, ref_p = hip.t["params"][: hip.num_params], pt.flat_params(ac)
         bad = (got_p - ref_p).abs() > (2e-6 + 1e-4 * ref_p.abs())
         assert float(bad.float().mean()) < 5e-4, float(bad.float().mean())
         assert float((got_p - ref_p).abs().max()) <= 2.1 * algo.learning_rate * (mb + 1)
+        if mb == 0 and bool(bad.any()):                    # (after the first step the Adam moments carry step 0's noise as well)
+            gerr, gmag = (g_got - g_ref).abs()[bad], g_ref.abs()[bad]
+            explained = (gerr >= 0.02 * gmag) | (gmag <= 1e-6 * scale)
+            assert bool(explained.all()), (int((~explained).sum()), int(bad.sum()))
     hip.close()
 
 

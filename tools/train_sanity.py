@@ -2,8 +2,9 @@
 
     python tools/train_sanity.py ITERS [HIDDEN] [MODE] [ROBOT]
 
-ROBOT "anymal_c" (default, actuator net, plane), "a1" (Unitree A1, PD law, plane) or "anymal_c_rough" (mixed terrain
-with the height scan and the terrain curriculum).
+ROBOT "anymal_c" (default, actuator net, plane), "a1" (Unitree A1, PD law, plane), "anymal_c_rough" (mixed terrain
+with the height scan and the terrain curriculum) or "anymal_c_trajectory" (the trajectory-tracking task anymal_c_flat_trajectory
+with the reward table the fork's authors launch it with, deep_tube_learning/configs/rl/default.yaml:29-39: tracking_rom 6, ...).
 
 MODE "ref"  : the fork's anymal_c_flat config as committed (its reward is identically 0 after the
               positive clip: commands x,y are 0 so feet_air_time never pays).
@@ -34,6 +35,14 @@ EnvCls = Anymal
 if robot == "anymal_c_rough":
     from legged_gym_dev_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg, AnymalCRoughCfgPPO
     env_cfg, train_cfg = AnymalCRoughCfg(), AnymalCRoughCfgPPO()
+if robot == "anymal_c_trajectory":
+    from legged_gym_dev_amd.envs.anymal_c.anymal_trajectory import AnymalTrajectory as EnvCls
+    from legged_gym_dev_amd.envs.anymal_c.flat_trajectory.anymal_c_flat_trajectory_config import AnymalCFlatTrajectoryCfg, AnymalCFlatTrajectoryCfgPPO
+    env_cfg, train_cfg = AnymalCFlatTrajectoryCfg(), AnymalCFlatTrajectoryCfgPPO()
+    for k, v in dict(termination=-0.5, tracking_rom=6.0, ang_vel_xy=-0.05, orientation=-1.0, torques=-1e-5, dof_acc=-2.5e-7, collision=-1.0,
+                     action_rate=-0.1, feet_air_time=0.0).items():
+        setattr(env_cfg.rewards.scales, k, v)
+    mode = "as launched by the authors"
 if robot == "a1":
     from legged_gym_dev_amd.envs.a1.a1_config import A1RoughCfg, A1RoughCfgPPO
     from legged_gym_dev_amd.envs.base.legged_robot import LeggedRobot as EnvCls
@@ -71,9 +80,13 @@ for it in range(iters):
         n = max(es[2], 1)
         bad = int((~torch.isfinite(env.root_states).all(1)).sum()) + int((~torch.isfinite(env.obs_buf).all(1)).sum())
         lvl = float(env.terrain_levels.float().mean()) if hasattr(env, "terrain_levels") else 0.0
-        trk = float(env.extras["episode"].get("rew_tracking_lin_vel", torch.zeros(()))) if "episode" in env.extras else 0.0
+        trk_key = "rew_tracking_rom" if robot == "anymal_c_trajectory" else "rew_tracking_lin_vel"
+        trk = float(env.extras["episode"].get(trk_key, torch.zeros(()))) if "episode" in env.extras else 0.0
+        if robot == "anymal_c_trajectory":
+            terr = float((env.trajectory[:, 0] - env.root_states[:, :2]).norm(dim=1).mean())
+            print(f"        mean distance to the reference trajectory {terr:.3f} m, physics faults {int(env.fault_total[0])}", flush=True)
         print(f"it {it + 1:4d}  mean_return {es[0] / n:8.3f}  mean_ep_len {es[1] / n:7.1f}  episodes {int(es[2]):6d}  "
               f"std {float(ppo.param_views['std'].mean()):.3f} lr {ppo.learning_rate:.2e} vloss {float(vl):.4f}  "
-              f"base_z {float(env.root_states[:, 2].mean()):.3f} rew_tracking_lin_vel {trk:.4f} terrain_level {lvl:.2f} nonfinite_envs {bad}", flush=True)
+              f"base_z {float(env.root_states[:, 2].mean()):.3f} rew_tracking {trk:.4f} terrain_level {lvl:.2f} nonfinite_envs {bad}", flush=True)
 dt = time.time() - t0
 print(f"{iters} iterations in {dt:.1f}s -> {iters * 24 * 4096 / dt:.0f} env-steps/s incl. logging")
