@@ -16,6 +16,8 @@ void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s);
 void ppok_sync_planes(const PpoDev *P, hipStream_t s);
 int ppok_mlp_fwd(const MlpArgs *g, int mask, hipStream_t s);
 void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s);
+void ppok_debug_set_xcd_remap(int v);
+void ppok_debug_set_dw_t(int v);
 void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const float *mu, const float *val, int t,
                      int64_t cnt, int inject, hipStream_t s);
 void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, const uint8_t *tos, int t, hipStream_t s);
@@ -161,6 +163,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         int splits = (int)((dw_target + tiles - 1) / tiles);
         int max_splits = M / 256 > 0 ? M / 256 : 1;
         if (splits > max_splits) splits = max_splits;
+        if (splits >= 8) splits &= ~7;                 // whole groups of 8 slices: one per XCD (xcd_tile)
         if (splits < 1) splits = 1;
         hipStream_t dw_stream = p->overlap ? p->side : p->stream;
         if (p->overlap) {                            // dz[l+1] is complete on the main stream at this point
@@ -238,6 +241,8 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     }
     p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0;
     p->comm = nullptr; p->comm_rc = 0;
+    if (getenv("LG_XCD_REMAP")) ppok_debug_set_xcd_remap(atoi(getenv("LG_XCD_REMAP")));
+    if (getenv("LG_DW_T")) ppok_debug_set_dw_t(atoi(getenv("LG_DW_T")));
     p->perm_count = 0;
     const int R = (int)((long)N * T / cfg->num_mini_batches);
     p->Mmax = R > N ? R : N;

@@ -37,6 +37,22 @@ __device__ __forceinline__ float act_bwd(int code, float a) {
     }
 }
 
+// XCD-aware workgroup -> tile map.  The 8 XCDs of an MI355X have private L2s and workgroups are dealt to them round-robin by
+// linear workgroup id, so neighbouring ids -- the column tiles of one row block, the output tiles of one reduction slice --
+// land on 8 different L2s and each fetches its own copy of the operand rows they share.  remap(l) regroups the ids so that
+// the `inner` workgroups that share operand rows get the same XCD: XCD c owns outer indices c, c + 8, ...
+static __device__ int g_xcd_remap = 1;
+__device__ __forceinline__ void xcd_tile(int lin, int inner, int outer, int &o, int &i) {
+    if (g_xcd_remap && (outer & 7) == 0) {
+        const int c = lin & 7, j = lin >> 3;
+        o = c + 8 * (j / inner);
+        i = j % inner;
+    } else {
+        o = lin / inner;
+        i = lin % inner;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = opA(A) . opB(B), K = reduction length.  A_RC: A stored [m][k] (reduction contiguous),
 // else [k][m].  B_RC: B stored [n][k], else [k][n].  4 waves as 2x2, each TM x TN tiles of 32x32
@@ -558,7 +574,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
     const int M = g.M[z], N = g.N[z], K = g.K[z];
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     if ((int)blockIdx.x >= tiles_n * tiles_m) return;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    int tm, tn;
+    if (EPI == 2) { tm = blockIdx.x / tiles_n; tn = blockIdx.x % tiles_n; }
+    else xcd_tile((int)blockIdx.x, tiles_n, tiles_m, tm, tn);      // the column tiles of a row block share the A rows: one XCD
     const int m0 = tm * BM, n0 = tn * BN;
     // reduction range of this workgroup (split only used by EPI 2)
     int k_begin = 0, k_end = K;
@@ -615,6 +633,139 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
     else if (g.elu == 0) gemm_epilogue<EPI, TM, TN, BM, BN, 0>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
     else gemm_epilogue<EPI, TM, TN, BM, BN, -1>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient dW[M][N] += A^T . B over a slice of the minibatch rows, A = dz [k][m], B = act [k][n], both with the
+// REDUCTION index as the row index in memory.  Both k-tiles are staged the way they lie in HBM -- [32 k-rows][BM | BN columns],
+// float4 along the rows, split into the three bf16 planes on the way (8-byte LDS stores, consecutive lanes on consecutive
+// half-chunks) -- and every operand fragment (8 consecutive k of one column per lane) comes out of the transposing LDS read,
+// as in the input-gradient kernel.  The k_gemm<false,false,2,...> path it replaces transposed while staging: 4-byte stores
+// scattered over four physical rows per float4, 4-way bank conflicts, 2.7 us per k-tile with a CU to itself.
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_store_x6t(unsigned char *__restrict__ lds, const float4 (&regs)[ROWS * BK / 4 / NT], unsigned mask) {
+    constexpr int NV = ROWS * BK / 4 / NT, PL = plt_plane_bytes<ROWS>();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int idx = threadIdx.x + v * NT;
+        const int c = idx & (ROWS / 4 - 1), r = idx / (ROWS / 4);          // float4 c of k-row r (stage_load<false,...> mapping)
+        const bool in = (mask >> v) & 1u;
+        const float x0 = in ? regs[v].x : 0.f, x1 = in ? regs[v].y : 0.f, x2 = in ? regs[v].z : 0.f, x3 = in ? regs[v].w : 0.f;
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split2(x0, x1, h0, m0, l0);
+        split2(x2, x3, h1, m1, l1);
+        unsigned char *d = lds + plt_off<ROWS>(r, c >> 1) + 8 * (c & 1);
+        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(d + PL) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2 *>(d + 2 * PL) = make_uint2(l0, l1);
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm_dw_t(GemmArgs g) {
+    constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
+    constexpr int APL = plt_plane_bytes<BM>(), BPL = plt_plane_bytes<BN>();
+    constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;
+    const int z = blockIdx.z;
+    const int M = g.M[z], N = g.N[z], K = g.K[z];
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_n * tiles_m) return;
+    int slice, tile;                                               // the output tiles of one reduction slice share its rows: one XCD
+    xcd_tile((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y, slice, tile);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int per = ((K + gridDim.y - 1) / gridDim.y + BK - 1) / BK * BK;
+    const int k_begin = slice * per, k_end = min(K, k_begin + per);
+    if (k_begin >= k_end) return;
+    const float *__restrict__ A = g.A[z];
+    const float *__restrict__ B = g.B[z];
+    const int lda = g.lda[z], ldb = g.ldb[z], ldc = g.ldc[z];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * (APL + BPL)];
+    unsigned char *lds_b = lds + 3 * APL;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = (wave / WGN) * 32 * TM, wn = (wave % WGN) * 32 * TN;
+    const int li = lane & 31, lk = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // transposed-read bases (T10): group tg = lane >> 4 takes columns 16 (tg & 1) .. +15 and k-rows 8 (tg >> 1) + 4 h .. +3
+    const int tg = (threadIdx.x >> 4) & 3, tq = (threadIdx.x >> 2) & 3, tp = threadIdx.x & 3;
+    const unsigned char *fa[2], *fb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int lane_off = 64 * (4 * h + tq) + 16 * ((2 * (tg & 1) + (tp >> 1)) ^ (2 * (tg >> 1) + h)) + 8 * (tp & 1);
+        fa[h] = lds + (BM / 32 * 512) * (tg >> 1) + 512 * (wm / 32) + lane_off;
+        fb[h] = lds_b + (BN / 32 * 512) * (tg >> 1) + 512 * (wn / 32) + lane_off;
+    }
+    auto frag = [&](const unsigned char *const (&f)[2], int o) -> bf16x8 {
+        const s16x4 lo = lds_read_tr16(f[0] + o), hi = lds_read_tr16(f[1] + o);
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    const bool a_vec = (lda & 3) == 0 && ((uintptr_t)A & 15) == 0 && (M & 3) == 0 && M >= 4;
+    const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (N & 3) == 0 && N >= 4;
+    float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
+    unsigned ma0, mb0, ma1 = 0, mb1 = 0;
+    auto load = [&](int k0, float4 (&ra)[NVA], float4 (&rb)[NVB], unsigned &ma, unsigned &mb) {
+        if (a_vec) stage_load<false, BM, true, false, NT>(A, lda, m0, k0, M, k_end, ra, ma);
+        else stage_load<false, BM, false, false, NT>(A, lda, m0, k0, M, k_end, ra, ma);
+        if (b_vec) stage_load<false, BN, true, false, NT>(B, ldb, n0, k0, N, k_end, rb, mb);
+        else stage_load<false, BN, false, false, NT>(B, ldb, n0, k0, N, k_end, rb, mb);
+    };
+    load(k_begin, ra0, rb0, ma0, mb0);
+    if (k_begin + BK < k_end) load(k_begin + BK, ra1, rb1, ma1, mb1);
+    stage_store_x6t<BM, NT>(lds, ra0, ma0);
+    stage_store_x6t<BN, NT>(lds_b, rb0, mb0);
+    __syncthreads();
+    auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA], float4 (&yb)[NVB],
+                    unsigned &yma, unsigned &ymb) {
+        if (k0 + 2 * BK < k_end) load(k0 + 2 * BK, ya, yb, yma, ymb);     // two k-tiles ahead, into the set just consumed
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 av[TM][3], bv[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) av[a][p] = frag(fa, 512 * a + p * APL + (BM / 32 * 512) * 2 * s);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bv[b][p] = frag(fb, 512 * b + p * BPL + (BN / 32 * 512) * 2 * s);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const bf16x8 *x = av[a], *y = bv[b];
+                    f32x16 c = acc[a][b];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+        }
+        __syncthreads();
+        if (k0 + BK < k_end) {
+            stage_store_x6t<BM, NT>(lds, xa, xma);
+            stage_store_x6t<BN, NT>(lds_b, xb, xmb);
+        }
+        __syncthreads();
+    };
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+        body(k0, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
+        if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
+    }
+    gemm_epilogue<2, TM, TN, BM, BN, 1>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
+}
+
+extern "C" void ppok_debug_set_xcd_remap(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_remap), &v, sizeof(int)); }
+static int g_gemm_dw_t = 1;    // weight gradients through k_gemm_dw_t (0: the transposing-store path of k_gemm, for A/B)
+extern "C" void ppok_debug_set_dw_t(int v) { g_gemm_dw_t = v; }
 
 static int g_gemm_dbuf = 0;   // single LDS buffer (34 KB, 4 workgroups/CU) measured 3-15 % faster than double buffering
 extern "C" void ppok_debug_set_dbuf(int v) { g_gemm_dbuf = v; }
@@ -695,7 +846,18 @@ extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s) {
     if (planes_t_ok(*g, nz)) launch_gemm_pl<1, false, 2>(*g, nz, s);
     else launch_gemm<true, false, 1>(*g, nz, 1, s);
 }
-extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s) { launch_gemm<false, false, 2>(*g, nz, splits, s); }
+extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s) {
+    if (!(g_gemm_dw_t && g_gemm_x6)) { launch_gemm<false, false, 2>(*g, nz, splits, s); return; }
+    int maxM = 0, maxN = 0;
+    for (int z = 0; z < nz; ++z) { maxM = g->M[z] > maxM ? g->M[z] : maxM; maxN = g->N[z] > maxN ? g->N[z] : maxN; }
+    const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
+    if (big_tiles * splits >= 192 && maxN > 64 && maxM > 64) {
+        hipLaunchKernelGGL((k_gemm_dw_t<2, 1, 2, 4>), dim3((unsigned)big_tiles, splits, nz), dim3(512), 0, s, *g);
+    } else {
+        const unsigned tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);
+        hipLaunchKernelGGL((k_gemm_dw_t<1, 1, 2, 2>), dim3(tiles, splits, nz), dim3(256), 0, s, *g);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // PPO.act epilogue: a ~ N(mu, sigma), log-prob, transition store (rsl_rl PPO.act / storage.add)
@@ -1336,7 +1498,7 @@ extern "C" void ppok_debug_gemm(const float *A, const float *B, float *C, int M,
     g.A[0] = A; g.B[0] = B; g.C[0] = C; g.M[0] = M; g.N[0] = N; g.K[0] = K; g.ldc[0] = N;
     if (mode == 0) { g.lda[0] = K; g.ldb[0] = K; launch_gemm<true, true, 0>(g, 1, 1, (hipStream_t)stream); }
     else if (mode == 1) { g.lda[0] = K; g.ldb[0] = N; g.aux[0] = C; g.ldaux[0] = N; g.elu = 1; launch_gemm<true, false, 1>(g, 1, 1, (hipStream_t)stream); }
-    else { g.lda[0] = M; g.ldb[0] = N; launch_gemm<false, false, 2>(g, 1, splits, (hipStream_t)stream); }
+    else { g.lda[0] = M; g.ldb[0] = N; ppok_gemm_dw(&g, 1, splits, (hipStream_t)stream); }
 }
 
 // Debug entry for the weight-plane operand paths: W [rows][cols] fp32 is split into its three bf16 planes (caller-provided
