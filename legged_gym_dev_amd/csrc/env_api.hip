@@ -10,9 +10,10 @@ void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
 extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s);
-extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
-extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int64_t counter, int inject, int init_done, hipStream_t s);
+extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int N, int64_t counter, int inject, int init_done, int traj,
+                              hipStream_t s);
 
 #define HIPCHK(x)                                                                                  \
     do {                                                                                           \
@@ -232,7 +233,7 @@ int lg_compute_torques(lg_ctx *c) { return run_substeps(c, c->h.buf.actions, 1 /
 int lg_simulate(lg_ctx *c) { return run_substeps(c, c->h.buf.actions, 2 /*physics stage*/, 1); }
 int lg_post_physics_step(lg_ctx *c) {
     c->step_counter += 1;                                       // legged_robot.py:115
-    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
+    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, c->stream);
     return chk_launch();
 }
 int lg_reset_all(lg_ctx *c) {
@@ -247,7 +248,7 @@ int lg_debug_post_step_cycles(lg_ctx *c, unsigned long long *out /* host, 64 x 8
 int lg_reset_ids(lg_ctx *c, const int32_t *ids, int n) {        // legged_robot.py:147-187
     if (n < 0 || (n > 0 && !ids)) { g_err = "lg_reset_ids: bad id list"; return -1; }
     if (n == 0) return 0;                                       // :156-157
-    lgk_reset_ids(c->d, ids, n, c->step_counter, c->inject, c->init_done, c->stream);
+    lgk_reset_ids(c->d, ids, n, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, c->stream);
     return chk_launch();
 }
 static int g_fused_substeps = 1;

@@ -804,9 +804,7 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
     if (n > 0) {
         if (tid < LG_NUM_TERMS)
             P->buf.extras_episode[tid] = term_scale(c, tid) != 0.0f ? (P->ep_accum[tid] / (float)n) / c.episode_length_s : 0.0f;
-        if (c.traj.enabled)                       // the reference's reset loop re-checks the hold time of EVERY env (lg_traj.h)
-            for (int i = tid; i < N; i += 256)
-                if (!P->reset_mark[i]) tg_late_resample(P, i, counter, inject);
+
         if (c.send_timeouts)
             for (int i = tid; i < N; i += 256) P->buf.extras_time_outs[i] = P->buf.time_out[i];
         if (c.curriculum) {
@@ -834,6 +832,14 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
         P->buf.n_fault[0] = nf; P->buf.fault_total[0] += nf; *P->fault_count = 0;
     }
     if (tid < LG_NUM_TERMS) P->ep_accum[tid] = 0.0f;
+}
+
+// Trajectory env, after the post-step (or lg_reset_ids) and before k_finalize: on a step where some env reset, the reference's
+// generator re-checks the hold time of EVERY env in its reset loop (lg_traj.h, tg_late_resample).  One lane per env.
+__global__ void __launch_bounds__(256) k_traj_late(const DevParams *__restrict__ P, int64_t counter, int inject) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P->cfg.num_envs || *P->reset_count <= 0) return;
+    if (!P->reset_mark[i]) tg_late_resample(P, i, counter, inject);
 }
 
 // reset_idx(env_ids) for a caller-given subset (LR:147-187): one workgroup per id.  The episode-sum means of the
@@ -876,15 +882,18 @@ extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L,
     else return -1;
     return 0;
 }
-extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, hipStream_t s) {
     constexpr int TILE = 16;
     hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done);
+    if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
 }
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);
 }
-extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int64_t counter, int inject, int init_done, hipStream_t s) {
+extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int N, int64_t counter, int inject, int init_done, int traj,
+                              hipStream_t s) {
     hipLaunchKernelGGL(k_reset_ids, dim3(n < 1024 ? n : 1024), dim3(LG_TILE_THREADS), 0, s, P, ids, n, counter, inject, init_done);
+    if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
 }

@@ -71,31 +71,52 @@ __device__ inline void tg_input(const DevParams *P, int i, float tt, float v[2])
     }
 }
 
-// RD:578-592 (SingleInt2D.f RD:192-193: z+ = z + rom_dt v)
-__device__ inline void tg_rom_step(const DevParams *P, int i, const float v[2]) {
-#pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
-    const lg_traj_cfg &t = P->cfg.traj;
-    const int npts = t.N * t.dN + 1;
-    float *z = P->buf.tg_traj + (size_t)i * npts * 2;
-    const float z0 = z[2 * (npts - 1)] + t.rom_dt * v[0], z1 = z[2 * (npts - 1) + 1] + t.rom_dt * v[1];
-    for (int p = 0; p + 1 < npts; ++p) { z[2 * p] = z[2 * (p + 1)]; z[2 * p + 1] = z[2 * (p + 1) + 1]; }
-    z[2 * (npts - 1)] = z0; z[2 * (npts - 1) + 1] = z1;
-    P->buf.tg_state[(size_t)i * LG_TG_STRIDE + LG_TG_K] += 1.0f;
-}
-
-// RD:610-615
-__device__ inline void tg_interpolate(const DevParams *P, int i) {
-#pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
-    const lg_traj_cfg &t = P->cfg.traj;
-    const int npts = t.N * t.dN + 1;
-    const float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
-    const float *z = P->buf.tg_traj + (size_t)i * npts * 2;
-    const float frac = s[LG_TG_T] - (s[LG_TG_K] - 1.0f) * t.rom_dt;
-    for (int p = 0; p < t.N; ++p)
+// The window of ROM states of env i, in registers: every load issued before the first store (the buffers may alias as far as
+// the compiler knows, so a load behind a store waits for it -- one exposed round trip per point for the lone lane otherwise).
+struct TgWindow { float z[2 * LG_TRAJ_MAX_PTS]; };
+__device__ inline void tg_window_load(const DevParams *P, int i, TgWindow &w) {
+    const int n2 = 2 * (P->cfg.traj.N * P->cfg.traj.dN + 1);
+    const float *z = P->buf.tg_traj + (size_t)i * n2;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const float a = z[2 * (p * t.dN) + d], b = z[2 * (p * t.dN + 1) + d];
-            P->buf.trajectory[((size_t)i * t.N + p) * 2 + d] = a + (b - a) * frac / t.rom_dt;
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; ++p) w.z[p] = p < n2 ? z[p] : 0.0f;
+}
+__device__ inline void tg_window_store(const DevParams *P, int i, const TgWindow &w) {
+    const int n2 = 2 * (P->cfg.traj.N * P->cfg.traj.dN + 1);
+    float *z = P->buf.tg_traj + (size_t)i * n2;
+#pragma unroll
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; ++p)
+        if (p < n2) z[p] = w.z[p];
+}
+// RD:578-592 (SingleInt2D.f RD:192-193: z+ = z + rom_dt v): shift the window by one point and append the new state
+__device__ inline void tg_window_step(const DevParams *P, TgWindow &w, const float v[2]) {
+#pragma clang fp contract(off)
+    const lg_traj_cfg &t = P->cfg.traj;
+    const int n2 = 2 * (t.N * t.dN + 1);
+    float last0 = 0.0f, last1 = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; p += 2)
+        if (p == n2 - 2) { last0 = w.z[p]; last1 = w.z[p + 1]; }
+    const float z0 = last0 + t.rom_dt * v[0], z1 = last1 + t.rom_dt * v[1];
+#pragma unroll
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS - 2; ++p) w.z[p] = w.z[p + 2];
+#pragma unroll
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; p += 2)
+        if (p == n2 - 2) { w.z[p] = z0; w.z[p + 1] = z1; }
+}
+// RD:610-615: the window interpolated at the env's time (t, k already advanced)
+__device__ inline void tg_window_interpolate(const DevParams *P, int i, const TgWindow &w, float tnow, float know) {
+#pragma clang fp contract(off)
+    const lg_traj_cfg &t = P->cfg.traj;
+    const float frac = tnow - (know - 1.0f) * t.rom_dt;
+    float *out = P->buf.trajectory + (size_t)i * t.N * 2;
+#pragma unroll
+    for (int p = 0; p < LG_TRAJ_MAX_PTS - 1; ++p)
+        if (p < t.N) {                                   // dN == 1 (checked at lg_create): points p and p + 1
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float a = w.z[2 * p + d], b = w.z[2 * p + 2 + d];
+                out[2 * p + d] = a + (b - a) * frac / t.rom_dt;
+            }
         }
 }
 
@@ -104,14 +125,21 @@ __device__ inline void tg_callback_step(const DevParams *P, int i, int64_t count
 #pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
     const lg_traj_cfg &t = P->cfg.traj;
     float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
+    TgWindow w;
+    tg_window_load(P, i, w);
     const float tt = s[LG_TG_T];
     if (tt > s[LG_TG_T_FINAL]) tg_resample(P, i, LG_TSLOT_TG, counter, inject);
     float v[2];
     tg_input(P, i, tt, v);
+    float k = s[LG_TG_K];
+    const bool rom = tt >= k * t.rom_dt - 1e-5f;
+    if (rom) { tg_window_step(P, w, v); k += 1.0f; }
+    const float tn = tt + P->cfg.dt;
     s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];                      // self.v (RD:579-580)
-    if (tt >= s[LG_TG_K] * t.rom_dt - 1e-5f) tg_rom_step(P, i, v);
-    s[LG_TG_T] = tt + P->cfg.dt;
-    tg_interpolate(P, i);
+    s[LG_TG_K] = k;
+    s[LG_TG_T] = tn;
+    if (rom) tg_window_store(P, i, w);
+    tg_window_interpolate(P, i, w, tn, k);
 }
 
 // RD:597-608 with the start state z0 (LT:222-229)
@@ -120,20 +148,27 @@ __device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y,
     const lg_traj_cfg &t = P->cfg.traj;
     const int npts = t.N * t.dN + 1, A = P->cfg.num_actions;
     float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
-    float *z = P->buf.tg_traj + (size_t)i * npts * 2;
-    for (int p = 0; p < 2 * npts; ++p) z[p] = 0.0f;
-    z[2 * (npts - 1)] = z0x; z[2 * (npts - 1) + 1] = z0y;
+    TgWindow w;
+#pragma unroll
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; ++p) w.z[p] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; p += 2)
+        if (p == 2 * (npts - 1)) { w.z[p] = z0x; w.z[p + 1] = z0y; }
     s[LG_TG_K] = -(float)(t.N * t.dN);
     s[LG_TG_T] = s[LG_TG_K] * t.rom_dt;
     s[LG_TG_T_FINAL] = s[LG_TG_K] * t.rom_dt;
     tg_resample(P, i, LG_TSLOT_RTG(A), counter, inject);
+    float tt = s[LG_TG_T], k = s[LG_TG_K], v[2] = {0.0f, 0.0f};
     for (int it = 0; it < t.N * t.dN; ++it) {
-        float v[2];
-        tg_input(P, i, s[LG_TG_T], v);
-        s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];
-        tg_rom_step(P, i, v);
-        s[LG_TG_T] += t.rom_dt;
+        tg_input(P, i, tt, v);
+        tg_window_step(P, w, v);
+        k += 1.0f;
+        tt += t.rom_dt;
     }
+    s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];
+    s[LG_TG_K] = k;
+    s[LG_TG_T] = tt;
+    tg_window_store(P, i, w);
 }
 
 // the reset loop's get_input_t reaches every env (RD:579): see legged_hip.h LG_TSLOT_RTG
