@@ -805,8 +805,12 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
         if (tid < LG_NUM_TERMS)
             P->buf.extras_episode[tid] = term_scale(c, tid) != 0.0f ? (P->ep_accum[tid] / (float)n) / c.episode_length_s : 0.0f;
 
-        if (c.send_timeouts)
-            for (int i = tid; i < N; i += 256) P->buf.extras_time_outs[i] = P->buf.time_out[i];
+        if (c.send_timeouts) {                       // byte masks, 16 per lane and trip (hipMalloc'ed: 256-byte aligned)
+            const int n16 = N >> 4;
+            for (int i = tid; i < n16; i += 256)
+                reinterpret_cast<uint4 *>(P->buf.extras_time_outs)[i] = reinterpret_cast<const uint4 *>(P->buf.time_out)[i];
+            for (int i = (n16 << 4) + tid; i < N; i += 256) P->buf.extras_time_outs[i] = P->buf.time_out[i];
+        }
         if (c.curriculum) {
             float s = 0.0f;
             for (int i = tid; i < N; i += 256) s += (float)P->buf.terrain_levels[i];
@@ -820,9 +824,11 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
         }
     }
     __syncthreads();
-    __syncthreads();
-    if (n > 0 || c.traj.enabled)
-        for (int i = tid; i < N; i += 256) P->reset_mark[i] = 0;
+    if (n > 0 || c.traj.enabled) {
+        const int n16 = N >> 4;
+        for (int i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(P->reset_mark)[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = (n16 << 4) + tid; i < N; i += 256) P->reset_mark[i] = 0;
+    }
     if (tid < LG_NUM_TERMS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
     if (tid == 0) {
         P->buf.extras_episode_acc[LG_NUM_TERMS] += P->buf.extras_terrain_level[0];

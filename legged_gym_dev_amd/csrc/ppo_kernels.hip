@@ -1365,6 +1365,218 @@ __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__res
     }
 }
 
+// The same fused head with one network per workgroup (blockIdx.y: 0 actor, 1 critic).  The two heads share nothing but the
+// row index -- surrogate / entropy / KL need mu only, the value loss needs V only -- so each workgroup stages ONE activation
+// tile: 43 KB of LDS instead of 84, two workgroups per CU instead of one on 192 of the 256 CUs.  Used for H3 = 128, where
+// k_head_fused is one wave per SIMD.
+template <int H3>
+__global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__restrict__ xa_g, const float *__restrict__ xc_g,
+                                                     float *__restrict__ dza_g, float *__restrict__ dzc_g, int64_t w_a, int64_t b_a,
+                                                     int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c) {
+    constexpr int MA = LG_PPO_MAX_A, LDX = H3 + 1, NH = 256 / H3;
+    const int R = P.mb_rows, A = P.A, tid = threadIdx.x;
+    const bool actor = blockIdx.y == 0;
+    const float *__restrict__ x_g = actor ? xa_g : xc_g;
+    float *__restrict__ dz_g = actor ? dza_g : dzc_g;
+    const int nout = actor ? A : 1;
+    __shared__ float x[HEAD_ROWS * LDX];
+    __shared__ float w[MA * H3];
+    __shared__ float outs[HEAD_ROWS][MA + 1], douts[HEAD_ROWS][MA + 1];
+    __shared__ float red[2 * MA + 4], s_so2[MA], s_i2s2[MA], s_is2[MA], s_is[MA], s_lgs[MA], s_klc[MA];
+    if (tid < MA) {
+        const float sg = tid < A ? P.params[P.off_std + tid] : 1.f, so = tid < A ? P.st_sigma[tid] : 1.f;
+        s_so2[tid] = so * so; s_i2s2[tid] = 1.0f / (2.0f * sg * sg); s_is2[tid] = 1.0f / (sg * sg); s_is[tid] = 1.0f / sg;
+        s_lgs[tid] = logf(sg) + 0.9189385332046727f; s_klc[tid] = logf(sg / so + 1.e-5f) - 0.5f;
+    }
+    for (int i = tid; i < nout * H3; i += 256) w[i] = P.params[(actor ? w_a : w_c) + i];
+    if (tid < 2 * MA + 4) red[tid] = 0.f;
+    const int c = tid % H3, half = tid / H3;
+    float dw[MA], db_prev = 0.f, part[2 * MA + 4];
+#pragma unroll
+    for (int a = 0; a < MA; ++a) dw[a] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * MA + 4; ++k) part[k] = 0.f;
+    const int ntiles = (R + HEAD_ROWS - 1) / HEAD_ROWS;
+    const float invR = 1.0f / (float)R;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = tile * HEAD_ROWS;
+        __syncthreads();
+        {
+            constexpr int NV = HEAD_ROWS * H3 / 4 / 256;
+            float4 vx[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = tid + v * 256, r = i / (H3 / 4), c4 = i % (H3 / 4);
+                vx[v] = *reinterpret_cast<const float4 *>(x_g + (size_t)min(r0 + r, R - 1) * H3 + 4 * c4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = tid + v * 256, r = i / (H3 / 4), c4 = i % (H3 / 4);
+                float *d = x + r * LDX + 4 * c4;
+                d[0] = vx[v].x; d[1] = vx[v].y; d[2] = vx[v].z; d[3] = vx[v].w;
+            }
+        }
+        __syncthreads();
+        {   // forward: lane = row; wave wv takes outputs wv, wv + 4, ... (critic: the four waves split k and meet in LDS)
+            const int r = tid & 63, wv = tid >> 6;
+            const float *xr = x + r * LDX;
+            if (actor) {
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                const float *w0 = w + (wv < A ? wv : 0) * H3, *w1 = w + (wv + 4 < A ? wv + 4 : 0) * H3;
+                const float *w2 = w + (wv + 8 < A ? wv + 8 : 0) * H3, *w3 = w + (wv + 12 < A ? wv + 12 : 0) * H3;
+#pragma unroll 8
+                for (int k = 0; k < H3; ++k) {
+                    const float xv = xr[k];
+                    o0 += xv * w0[k]; o1 += xv * w1[k]; o2 += xv * w2[k]; o3 += xv * w3[k];
+                }
+                if (wv < A) outs[r][wv] = o0 + P.params[b_a + wv];
+                if (wv + 4 < A) outs[r][wv + 4] = o1 + P.params[b_a + wv + 4];
+                if (wv + 8 < A) outs[r][wv + 8] = o2 + P.params[b_a + wv + 8];
+                if (wv + 12 < A) outs[r][wv + 12] = o3 + P.params[b_a + wv + 12];
+            } else {
+                float o = 0.f;
+#pragma unroll 8
+                for (int k = wv * (H3 / 4); k < (wv + 1) * (H3 / 4); ++k) o += xr[k] * w[k];
+                outs[r][wv] = o;                            // four partial sums per row
+            }
+        }
+        __syncthreads();
+        if (tid < HEAD_ROWS) {                              // loss of one row (the arithmetic of k_loss), wave 0
+            const int r = r0 + tid;
+            const size_t rr = (size_t)min(r, R - 1);
+            const float4 sc = reinterpret_cast<const float4 *>(P.mb_scalars)[rr];
+#pragma unroll
+            for (int a = 0; a <= MA; ++a) douts[tid][a] = 0.f;
+            if (actor) {
+                float act_r[MA], mo_r[MA];
+#pragma unroll
+                for (int a = 0; a < MA; ++a) {
+                    const int ac = min(a, A - 1);
+                    act_r[a] = P.mb_actions[rr * A + ac];
+                    mo_r[a] = P.mb_mu[rr * A + ac];
+                }
+                if (r < R) {
+                    const float adv = sc.z, lp_old = sc.w;
+                    float lp = 0.f, kl = 0.f, dd[MA];
+#pragma unroll
+                    for (int a = 0; a < MA; ++a) {
+                        dd[a] = 0.f;
+                        if (a < A) {
+                            const float m = outs[tid][a], mo = mo_r[a];
+                            const float d = act_r[a] - m;
+                            dd[a] = d;
+                            lp += -(d * d) * s_i2s2[a] - s_lgs[a];
+                            kl += s_klc[a] + (s_so2[a] + (mo - m) * (mo - m)) * s_i2s2[a];
+                        }
+                    }
+                    const float ratio = expf(lp - lp_old);
+                    const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+                    const float s1 = -adv * ratio, s2 = -adv * rc;
+                    const float dl_dlp = (s1 >= s2 ? -adv : 0.0f) * ratio * invR;
+#pragma unroll
+                    for (int a = 0; a < MA; ++a)
+                        if (a < A) {
+                            const float d = dd[a];
+                            const float g = dl_dlp * d * s_is2[a];
+                            douts[tid][a] = g;
+                            part[MA + a] += g;
+                            part[a] += dl_dlp * (d * d * s_is2[a] * s_is[a] - s_is[a]) - P.entropy_coef * invR * s_is[a];
+                        }
+                    part[2 * MA + 1] += kl;
+                    part[2 * MA + 3] += fmaxf(s1, s2);
+                }
+            } else if (r < R) {
+                const float v_old = sc.x, ret = sc.y;
+                const float v = P.params[b_c] + ((outs[tid][0] + outs[tid][1]) + (outs[tid][2] + outs[tid][3]));
+                float lv, dv;
+                if (P.clipped_value) {
+                    const float dvv = v - v_old;
+                    const float vc = v_old + fminf(fmaxf(dvv, -P.clip), P.clip);
+                    const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+                    const float inside = (dvv >= -P.clip && dvv <= P.clip) ? 1.0f : 0.0f;
+                    lv = fmaxf(l1, l2);
+                    if (l1 > l2) dv = 2.0f * (v - ret);
+                    else if (l1 < l2) dv = 2.0f * (vc - ret) * inside;
+                    else dv = (v - ret) + (vc - ret) * inside;
+                } else {
+                    lv = (ret - v) * (ret - v);
+                    dv = 2.0f * (v - ret);
+                }
+                const float dvl = dv * P.value_coef * invR;
+                douts[tid][0] = dvl;
+                part[2 * MA] += dvl;
+                part[2 * MA + 2] += lv;
+            }
+        }
+        __syncthreads();
+        if (half < NH) {                                    // backward for column c: dz = (dout . W) act'(x); dW += dout^T x
+            float wcol[MA];
+#pragma unroll
+            for (int a = 0; a < MA; ++a) wcol[a] = a < nout ? w[a * H3 + c] : 0.f;
+            for (int r = half; r < HEAD_ROWS && r0 + r < R; r += NH) {
+                const float xv = x[r * LDX + c];
+                float g = 0.f;
+                if (actor) {
+#pragma unroll
+                    for (int a = 0; a < MA; ++a) {
+                        const float dm = douts[r][a];
+                        g += dm * wcol[a];
+                        dw[a] += dm * xv;
+                    }
+                } else {
+                    const float dv = douts[r][0];
+                    g = dv * wcol[0];
+                    dw[0] += dv * xv;
+                }
+                const float dz = g * (xv > 0.f ? 1.0f : xv + 1.0f);
+                dz_g[(size_t)(r0 + r) * H3 + c] = dz;
+                db_prev += dz;
+            }
+        }
+    }
+    if (tid < HEAD_ROWS) {
+#pragma unroll
+        for (int k = 0; k < 2 * MA + 4; ++k) {
+            if (k >= 2 * MA || (k % MA) < A) {
+                float v = part[k];
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+                if (tid == 0) red[k] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * MA + 4) {
+        const int k = tid;
+        const float v = red[k];
+        if (actor) {
+            if (k < MA) { if (k < A) atomicAdd(&P.grads[P.off_std + k], v); }
+            else if (k < 2 * MA) { if (k - MA < A) atomicAdd(&P.grads[b_a + (k - MA)], v); }
+            else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);
+            else if (k == 2 * MA + 3) atomicAdd(&P.loss_acc[1], v);
+        } else {
+            if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
+            else if (k == 2 * MA + 2) atomicAdd(&P.loss_acc[0], v);
+        }
+    }
+    float *acc = x;                                         // reuse the tile buffer: [MA + 1][NH][H3]
+    __syncthreads();
+    if (half < NH) {
+#pragma unroll
+        for (int a = 0; a < MA; ++a) acc[(a * NH + half) * H3 + c] = dw[a];
+        acc[(MA * NH + half) * H3 + c] = db_prev;
+    }
+    __syncthreads();
+    for (int i = tid; i < (MA + 1) * H3; i += 256) {
+        const int q = i / H3, cc = i % H3;
+        float v = 0.f;
+        for (int h = 0; h < NH; ++h) v += acc[(q * NH + h) * H3 + cc];
+        if (q < MA) { if (q < nout) atomicAdd(&P.grads[(actor ? w_a : w_c) + (int64_t)q * H3 + cc], v); }
+        else atomicAdd(&P.grads[(actor ? b_prev_a : b_prev_c) + cc], v);
+    }
+}
+
 // KL-adaptive learning rate (rsl_rl PPO.update) + reset of the norm accumulator
 // Optimiser step in two launches.  k_opt_prepare: squared gradient norm (block partials -> atomics into
 // loss_acc[2 + par]) and, on one lane, the KL-adaptive learning rate, the loss statistics and the Adam step
@@ -1474,7 +1686,12 @@ int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, f
     const int ntiles = (P->mb_rows + HEAD_ROWS - 1) / HEAD_ROWS;
     static const int head_grid = getenv("LG_HEAD_GRID") ? atoi(getenv("LG_HEAD_GRID")) : HEAD_GRID;
     dim3 grid(ntiles < head_grid ? ntiles : head_grid), block(256);
-    if (H3 == 128) hipLaunchKernelGGL((k_head_fused<128>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+    static const int per_net = getenv("LG_HEAD_PER_NET") ? atoi(getenv("LG_HEAD_PER_NET")) : 1;
+    if (H3 == 128 && per_net) {
+        static const int net_grid = getenv("LG_HEAD_GRID") ? atoi(getenv("LG_HEAD_GRID")) : 384;
+        hipLaunchKernelGGL((k_head_net<128>), dim3(ntiles < net_grid ? ntiles : net_grid, 2), block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c,
+                           b_c, b_prev_a, b_prev_c);
+    } else if (H3 == 128) hipLaunchKernelGGL((k_head_fused<128>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else if (H3 == 64) hipLaunchKernelGGL((k_head_fused<64>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else if (H3 == 32) hipLaunchKernelGGL((k_head_fused<32>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else return -1;
