@@ -163,26 +163,49 @@ def single_gemm_roofline(rows, hidden, reps=20):
 
 
 def env_roofline(env, reps=50):
+    """lg_step against the two bounds that could apply.  HBM: 4.20 KB algorithmic per env-step -- nowhere near (the step is
+    latency-bound at 4096 envs: one workgroup per CU).  VALU issue: the control-loop kernel's critical wave (physics of 16 envs +
+    its share of the actuator net) executes `critical_wave_valu_per_lg_step` vector instructions (SQ_INSTS_VALU, committed PMC
+    pass profiles/*_substeps_pmc.json) and a wave64 issues at most one per 4 cycles; the clock is the wave's cycle count of the
+    same pass over the live duration."""
+    import ctypes
     a = torch.zeros(env.num_envs, env.num_actions, device=env.device)
     env.step(a)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        env.core.step(a)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms = timed(lambda: env.core.step(a))
+    ms_loop = timed(lambda: env.core.lib.lg_debug_control_loop(env.core.ctx, ctypes.c_void_p(a.data_ptr())))
     gbs = BYTES_PER_ENV_STEP * env.num_envs / (ms * 1e-3) / 1e9
-    traffic = None
+    traffic, pmc = None, None
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             traffic = json.load(f)["env_step_bytes_per_call"]
+        with open(os.path.join(ROOT, "profiles", PMC_FILE.replace("pmc_traffic", "substeps_pmc"))) as f:
+            pmc = json.load(f)
     except (OSError, ValueError, KeyError):
         pass
-    return {"bound": "hbm", "kernel": "lg_step (k_substeps: clip + 4 x {actuator net, physics} in one launch; k_post_step)", "achieved": round(gbs, 2),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "us_per_env_step_call": round(ms * 1e3, 2)}
+    out = {"bound": "valu-issue", "kernel": "k_substeps<4,3,true> (clip + 4 x {actuator net, ABA + contact}): one launch per policy step",
+           "us_per_launch": round(ms_loop * 1e3, 2), "us_per_lg_step": round(ms * 1e3, 2),
+           "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                   "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP}}
+    if pmc:
+        valu, cycles = pmc["critical_wave_valu_per_lg_step"], 4.0 * pmc["lg_step"]["wave_quad_cycles"]
+        clock = cycles / (ms_loop * 1e-3)                            # Hz the kernel's waves saw (DVFS: well under the 2.4 GHz peak)
+        out.update({"achieved": round(valu / (ms_loop * 1e-3) / 1e6, 1), "peak": round(clock / 4.0 / 1e6, 1), "unit": "M VALU instr/s per SIMD",
+                    "frac": round(4.0 * valu / cycles, 4), "critical_wave_valu": valu, "wave_cycles": cycles, "clock_ghz": round(clock / 1e9, 3),
+                    "source": "instruction and cycle counts: committed SQ counter pass (profiles/" + PMC_FILE.replace("pmc_traffic", "substeps_pmc")
+                              + "); durations: HIP events in this run"})
+    return out
 
 
 def cpu_baseline(num_envs, hidden):

@@ -251,6 +251,8 @@ int lg_reset_ids(lg_ctx *c, const int32_t *ids, int n) {        // legged_robot.
     lgk_reset_ids(c->d, ids, n, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, c->stream);
     return chk_launch();
 }
+// the control loop alone (clip + decimation x {torques, physics}), without the post-step: timing / profiling entry
+int lg_debug_control_loop(lg_ctx *c, const float *actions) { return run_substeps(c, actions, 3, c->h.cfg.decimation); }
 static int g_fused_substeps = 1;
 int lg_debug_set_fused(int v) { g_fused_substeps = v; return 0; }
 
