@@ -89,6 +89,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     c->init_done = 1;
     DevParams &h = c->h;
     h.cfg = *cfg;
+    for (int o = 0; o < LG_LSTM_LDS; ++o) h.lstm_img[o] = lstm_lds_image(cfg->lstm_w, o);
     h.model = *model;
     h.cfg.noise_vec = h.cfg.height_points = h.cfg.terrain_origins = nullptr;
     h.K = (cfg->traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A)) + O;
@@ -118,6 +119,8 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
             }
         }
         h.n_leg_slots = cnt[0];
+        h.slot_link_pk = 0ull;
+        for (int s = 0; s < h.n_leg_slots; ++s) h.slot_link_pk |= (unsigned long long)(h.slot_link[s] & 15) << (4 * s);
         for (int l = 1; l < L; ++l)
             if (cnt[l] != cnt[0]) { g_err = "legs differ in their number of collision spheres"; delete c; return -11; }
         if (J > LG_LT_MAXJ || L > 8) { g_err = "kinematic tree beyond the per-leg table"; delete c; return -12; }

@@ -2,7 +2,7 @@
 // post_physics_step (legged_gym/envs/base/legged_robot.py:80-226, "LR"), Anymal._compute_torques
 // (envs/anymal_c/anymal.py:71-81, "AN"), Cassie._reward_no_fly (envs/cassie/cassie.py:43-46, "CA").
 #include "lg_device.h"
-#include "lg_physics.h"
+#include "lg_physics_pair.h"
 #include "lg_traj.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -15,47 +15,82 @@ __global__ void k_set_actions(const DevParams *__restrict__ P, const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Actuator net, wide form: 8 lanes per (env, joint) row, lane k owns hidden unit k of both LSTM
-// layers (its 4 gate rows: 112 weights + lin_w[k], read from LDS).  The 8 hidden values of a row are
-// exchanged with width-8 shuffles; the state (2, N*A, 8) is read/written 4 B per lane, fully coalesced.
+// Actuator net, wide form: 8 lanes per (env, joint) row, lane k owns hidden unit k of both LSTM layers.  The 113 weights
+// lane k needs are staged once per block into one 16-byte aligned LDS record per k (stride 116 floats: the eight records'
+// b128 reads fall on disjoint banks) and read into VGPRs once per substep for all rows of the thread.  The 8 hidden values
+// of a row are exchanged with DPP only (quad broadcast + the xor-4 swap of lg_physics_pair.h), no LDS round trip: lane k
+// receives unit (k&4)+q from its own quad and unit ((k&4)^4)+q from the other and multiplies each by the matching weight,
+// so the lower and upper quads add the eight products in a different order.  All NR rows of a thread advance stage by
+// stage, which gives the scheduler NR independent chains to hide the exp / rcp latencies with.
 __device__ __forceinline__ float fsigm(float x) { return frcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * frcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
-
-// One actuator-net update of lane k (hidden unit k of both layers) of a row; w = the 972 weights in LDS.
-// Returns the row's output sum (reduced over the 8 lanes by butterflies).
-__device__ __forceinline__ float lstm8_update(const float *__restrict__ w, int k, float x0, float x1, float &h0, float &c0, float &h1,
-                                              float &c1) {
-    const float *wih0 = w + 3, *whh0 = wih0 + 64, *bih0 = whh0 + 256, *bhh0 = bih0 + 32;
-    const float *wih1 = bhh0 + 32, *whh1 = wih1 + 256, *bih1 = whh1 + 256, *bhh1 = bih1 + 32;
-    const float *lw = bhh1 + 32;
-    float g0[4], g1[4];
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float x) {                   // lane (i & ~3) + Q of every quad
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), Q * 0x55, 0xF, 0xF, true));
+}
+// g[r][gate] += sum_q W[gate][q] h_r[q] over the 8 units of the row; wo / wx = this lane's weights for the units of its own /
+// the other quad, [gate][q]
+template <int Q, int NR>
+__device__ __forceinline__ void lstm_acc_q(float (&g)[NR][4], const float (&h)[NR], const float (&wo)[4][4], const float (&wx)[4][4]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int r = g * 8 + k;
-        g0[g] = bih0[r] + bhh0[r] + wih0[r * 2] * x0 + wih0[r * 2 + 1] * x1;
-        g1[g] = bih1[r] + bhh1[r];
+    for (int r = 0; r < NR; ++r) {
+        const float b = quad_bcast<Q>(h[r]), x4 = lane_xor4(b);
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) g[r][gt] += wo[gt][Q] * b + wx[gt][Q] * x4;
+    }
+}
+template <int NR>
+__device__ __forceinline__ void lstm_acc(float (&g)[NR][4], const float (&h)[NR], const float *__restrict__ wm, int own4) {
+    float wo[4][4], wx[4][4];
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) {
+        const float4 a = *reinterpret_cast<const float4 *>(wm + gt * 8 + own4), b = *reinterpret_cast<const float4 *>(wm + gt * 8 + (own4 ^ 4));
+        wo[gt][0] = a.x; wo[gt][1] = a.y; wo[gt][2] = a.z; wo[gt][3] = a.w;
+        wx[gt][0] = b.x; wx[gt][1] = b.y; wx[gt][2] = b.z; wx[gt][3] = b.w;
+    }
+    lstm_acc_q<0, NR>(g, h, wo, wx);
+    lstm_acc_q<1, NR>(g, h, wo, wx);
+    lstm_acc_q<2, NR>(g, h, wo, wx);
+    lstm_acc_q<3, NR>(g, h, wo, wx);
+}
+// One actuator-net update of the NR rows of this thread (lane k = hidden unit k of both layers); wr = the LDS record of k.
+// y[r] = the row's output sum, in every lane of the row.
+template <int NR>
+__device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, const float (&x0)[NR], const float (&x1)[NR], float (&h0)[NR],
+                                           float (&c0)[NR], float (&h1)[NR], float (&c1)[NR], float (&y)[NR]) {
+    const int own4 = k & 4;
+    const float4 b0 = *reinterpret_cast<const float4 *>(wr), b1 = *reinterpret_cast<const float4 *>(wr + 4);
+    const float4 wa = *reinterpret_cast<const float4 *>(wr + 8), wb = *reinterpret_cast<const float4 *>(wr + 12);
+    const float bias0[4] = {b0.x, b0.y, b0.z, b0.w}, bias1[4] = {b1.x, b1.y, b1.z, b1.w};
+    const float wi[4][2] = {{wa.x, wa.y}, {wa.z, wa.w}, {wb.x, wb.y}, {wb.z, wb.w}};
+    float g[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) g[r][gt] = bias0[gt] + wi[gt][0] * x0[r] + wi[gt][1] * x1[r];
+    lstm_acc<NR>(g, h0, wr + 16, own4);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        c0[r] = fsigm(g[r][1]) * c0[r] + fsigm(g[r][0]) * ftanh(g[r][2]);
+        h0[r] = fsigm(g[r][3]) * ftanh(c0[r]);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float hq = __shfl(h0, q, 8);
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) g0[g] += whh0[(g * 8 + k) * 8 + q] * hq;
+        for (int gt = 0; gt < 4; ++gt) g[r][gt] = bias1[gt];
+    lstm_acc<NR>(g, h0, wr + 48, own4);
+    lstm_acc<NR>(g, h1, wr + 80, own4);
+    const float lw = wr[112];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        c1[r] = fsigm(g[r][1]) * c1[r] + fsigm(g[r][0]) * ftanh(g[r][2]);
+        h1[r] = fsigm(g[r][3]) * ftanh(c1[r]);
+        float t = lw * h1[r];
+        t += quad_xor1(t);
+        t += quad_xor2(t);
+        t += lane_xor4(t);
+        y[r] = t;
     }
-    c0 = fsigm(g0[1]) * c0 + fsigm(g0[0]) * ftanh(g0[2]);
-    h0 = fsigm(g0[3]) * ftanh(c0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float xq = __shfl(h0, q, 8), hq = __shfl(h1, q, 8);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) g1[g] += wih1[(g * 8 + k) * 8 + q] * xq + whh1[(g * 8 + k) * 8 + q] * hq;
-    }
-    c1 = fsigm(g1[1]) * c1 + fsigm(g1[0]) * ftanh(g1[2]);
-    h1 = fsigm(g1[3]) * ftanh(c1);
-    float y = lw[k] * h1;
-    y += __shfl_xor(y, 1, 8);
-    y += __shfl_xor(y, 2, 8);
-    y += __shfl_xor(y, 4, 8);
-    return y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -73,9 +108,10 @@ __device__ __forceinline__ float lstm8_update(const float *__restrict__ w, int k
 // sequence bit for bit (fp32 loads/stores between launches are exact; tests/test_hip_env.py asserts equality).
 #define LG_RUN_TORQUES 1
 #define LG_RUN_PHYSICS 2
-template <int L, int J, bool LSTM>
+template <int L, int J, bool LSTM, bool PAIR>
 __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
     constexpr int A = L * J, EPW = 64 / L, ROWS = EPW * A, NR = ROWS * 8 / 256;
+    constexpr int PW = PAIR ? 2 : 1, LPE = PAIR ? 2 * L : L;    // physics waves of the block, physics lanes per env
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -83,15 +119,22 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     const int env0 = blockIdx.x * EPW;
     const int nrow = min(ROWS, (N - env0) * A);              // live rows of this block
     const bool do_tau = mode & LG_RUN_TORQUES, do_phys = mode & LG_RUN_PHYSICS;
+    SubProf pr;
+#ifdef LG_PROF_SUBSTEPS
+    for (int k = 0; k < 16; ++k) pr.acc[k] = 0;
+    pr.last = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
     __shared__ float s_lt[L * LG_LT_STRIDE];
     __shared__ float s_lm[J * 4 * 64];
-    __shared__ float s_w[LSTM ? LG_LSTM_NW : 1];
+    __shared__ __attribute__((aligned(16))) float s_w[LSTM ? LG_LSTM_LDS : 4];
     __shared__ float s_act[ROWS], s_q[ROWS], s_qd[ROWS], s_tau[ROWS];
+    __shared__ float s_cf[EPW * LG_MAX_BODIES * 3];          // net contact force per (env, body) of the last control substep
+    for (int t = tid; t < EPW * LG_MAX_BODIES * 3; t += 256) s_cf[t] = 0.f;
     for (int t = tid; t < L * LG_LT_STRIDE; t += 256) s_lt[t] = (&P->leg_tab[0][0])[t];
     if (LSTM)
-        for (int t = tid; t < LG_LSTM_NW; t += 256) s_w[t] = c.lstm_w[t];
+        for (int t = tid; t < LG_LSTM_LDS; t += 256) s_w[t] = P->lstm_img[t];
     const size_t row0 = (size_t)env0 * A;
     for (int t = tid; t < ROWS; t += 256) {
         const bool in = t < nrow;
@@ -113,22 +156,25 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
             h0[r] = P->buf.lstm_h[idx]; c0[r] = P->buf.lstm_c[idx]; h1[r] = P->buf.lstm_h[ls + idx]; c1[r] = P->buf.lstm_c[ls + idx];
         }
     }
-    // physics lanes (wave 0)
-    int env = env0 + lane / L;
-    const int leg = lane % L;
+    // physics lanes: wave 0, one lane per (env, leg) -- or waves 0 and 1, two lanes per (env, leg) (lg_physics_pair.h);
+    // of a pair, lane h = 0 does the stores
+    const bool phys = wave < PW, hrole = PAIR && (tid & 1), writer = !hrole;
+    const int pe = (tid & (64 * PW - 1)) / LPE;              // env of this lane within the block
+    int env = env0 + pe;
+    const int leg = PAIR ? (tid >> 1) % L : tid % L;
     const bool live = env < N;
     if (!live) env = N - 1;
-    const int rl0 = (lane / L) * A + leg * J;                // first row of this lane's joints in the block
+    const int rl0 = pe * A + leg * J;                        // first row of this lane's joints in the block
     float root[13], q[J], qd[J], tau[J];
     float fr = 0.f, dm = 0.f;
-    if (wave == 0) {
+    if (phys) {
         const float *rp = P->buf.root_states + (size_t)env * 13;
 #pragma unroll
         for (int k = 0; k < 13; ++k) root[k] = rp[k];
         fr = P->buf.friction[env]; dm = P->buf.base_mass_delta[env];
     }
     __syncthreads();
-    if (wave == 0) {
+    if (phys) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int t = live ? rl0 + j : 0;
@@ -137,25 +183,30 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     }
     const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
-    float *cf = P->buf.contact_forces + (size_t)env * B * 3;
+    float *cf = s_cf + pe * B * 3;
+    PSTAMP(pr, 0);
     for (int sub = 0; sub < iters; ++sub) {
         // ---- torques
         if (do_tau) {
             if (LSTM) {                                                      // AN:71-81
+                float x0[NR], x1[NR], y[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const int rl = r * 32 + (tid >> 3), k = tid & 7;
-                    const int j = rl % A;
-                    const float x0 = (s_act[rl] * c.action_scale + c.default_dof_pos[j] - s_q[rl]) * s_w[0], x1 = s_qd[rl] * s_w[1];
-                    const float y = lstm8_update(s_w, k, x0, x1, h0[r], c0[r], h1[r], c1[r]);
-                    if (k == 0) s_tau[rl] = s_w[2] * (y + s_w[LG_LSTM_NW - 1]);
+                    const int rl = r * 32 + (tid >> 3);
+                    x0[r] = (s_act[rl] * c.action_scale + c.default_dof_pos[rl % A] - s_q[rl]) * s_w[0];
+                    x1[r] = s_qd[rl] * s_w[1];
+                }
+                lstm8_rows<NR>(s_w + 4 + (tid & 7) * LG_LSTM_REC, tid & 7, x0, x1, h0, c0, h1, c1, y);
+                if ((tid & 7) == 0) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) s_tau[r * 32 + (tid >> 3)] = s_w[2] * (y[r] + s_w[3]);
                 }
                 __syncthreads();
-                if (wave == 0) {
+                if (phys) {
 #pragma unroll
                     for (int j = 0; j < J; ++j) tau[j] = s_tau[live ? rl0 + j : 0];
                 }
-            } else if (wave == 0) {                                          // LR:389-413
+            } else if (phys) {                                               // LR:389-413
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     const int d = leg * J + j;
@@ -166,24 +217,28 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
                         t = c.p_gains[d] * (as - qd[j]) - c.d_gains[d] * (qd[j] - P->buf.last_dof_vel[(size_t)env * A + d]) / c.sim_dt;
                     else t = as;
                     tau[j] = clampf(t, -c.torque_limits[d], c.torque_limits[d]);
-                    if (live) s_tau[rl0 + j] = tau[j];
+                    if (live && writer) s_tau[rl0 + j] = tau[j];
                 }
             }
         }
+        PSTAMP(pr, 1);
         // ---- physics
-        if (do_phys && wave == 0) {
+        if (do_phys && phys) {
             const bool last = sub == iters - 1;
-            if (last && live)
-                for (int b = 0; b < B; ++b) {
-                    const int dyn = m.body_dyn[b];
-                    if ((dyn < 0 ? 0 : dyn / J) == leg) { cf[3 * b] = 0.f; cf[3 * b + 1] = 0.f; cf[3 * b + 2] = 0.f; }
-                }
             for (int s = 0; s < ns; ++s) {
                 V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-                const bool fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
-                if (fault && live && leg == 0) P->fault[env] = 1;
-                V3 fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
-                if (last && live) {
+                bool fault;
+                V3 fb;
+                if constexpr (PAIR) {
+                    fault = physics_pair<L, J>(P, leg, hrole, tid >> 1, tid, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk,
+                                               s_lk + J * LG_LKP_NF * 64, s_lt, s_lm, pr);
+                    fb = pleg_sum<L>(fbase);
+                } else {
+                    fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
+                    fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
+                }
+                if (fault && live && leg == 0 && writer) P->fault[env] = 1;
+                if (last && live && writer) {
 #pragma unroll
                     for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k)
                         if (k < P->n_leg_slots) {
@@ -196,14 +251,18 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
                     }
                 }
             }
-            if (live) {
+            if (live && writer) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) { s_q[rl0 + j] = q[j]; s_qd[rl0 + j] = qd[j]; }
             }
         }
+        PSTAMP(pr, 12);
         __syncthreads();
+        PSTAMP(pr, 13);
     }
     // ---- write back (once per launch)
+    if (do_phys)
+        for (int t = tid; t < min(EPW, N - env0) * B * 3; t += 256) P->buf.contact_forces[(size_t)env0 * B * 3 + t] = s_cf[t];
     for (int t = tid; t < nrow; t += 256) {
         if (do_phys) reinterpret_cast<float2 *>(P->buf.dof_state)[row0 + t] = make_float2(s_q[t], s_qd[t]);
         if (do_tau) P->buf.torques[row0 + t] = s_tau[t];
@@ -218,11 +277,16 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
             }
         }
     }
-    if (do_phys && wave == 0 && live && leg == 0) {
+    if (do_phys && phys && live && leg == 0 && writer) {
         float *wp = P->buf.root_states + (size_t)env * 13;
 #pragma unroll
         for (int k = 0; k < 13; ++k) wp[k] = root[k];
     }
+#ifdef LG_PROF_SUBSTEPS
+    PSTAMP(pr, 14);
+    if ((tid & 63) == 0 && wave < 2 && blockIdx.x < 16)
+        for (int k = 0; k < 16; ++k) P->dbg_cycles[(blockIdx.x * 2 + wave) * 16 + k] = pr.acc[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -880,11 +944,21 @@ extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipSt
     int blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_set_actions, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, P, a);
 }
+// LG_PHYS_PAIR=0 selects the one-lane-per-leg physics (lg_physics.h) for A/B runs; the default is the pair-lane map.
+static int phys_pair_enabled() {
+    static const int v = [] { const char *e = getenv("LG_PHYS_PAIR"); return e ? atoi(e) : 1; }();
+    return v;
+}
+template <int L, int J, bool LSTM>
+static void launch_substeps(int blocks, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {
+    if (phys_pair_enabled()) hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+    else hipLaunchKernelGGL((k_substeps<L, J, LSTM, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+}
 extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s) {
     const int blocks = (N + 64 / L - 1) / (64 / L);
-    if (L == 4 && J == 3 && lstm) hipLaunchKernelGGL((k_substeps<4, 3, true>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
-    else if (L == 4 && J == 3) hipLaunchKernelGGL((k_substeps<4, 3, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
-    else if (L == 2 && J == 6 && !lstm) hipLaunchKernelGGL((k_substeps<2, 6, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+    if (L == 4 && J == 3 && lstm) launch_substeps<4, 3, true>(blocks, P, a_in, mode, iters, s);
+    else if (L == 4 && J == 3) launch_substeps<4, 3, false>(blocks, P, a_in, mode, iters, s);
+    else if (L == 2 && J == 6 && !lstm) launch_substeps<2, 6, false>(blocks, P, a_in, mode, iters, s);
     else return -1;
     return 0;
 }

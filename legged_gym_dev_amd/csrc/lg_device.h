@@ -21,6 +21,24 @@
 #define LG_LT_STRIDE (LG_LT_BASE + 4 * LG_MAX_BASE_PER_LANE + 1)
 
 // Everything a kernel needs, resident in HBM and passed by pointer: uniform (scalar-unit) loads.
+// LDS image of the actuator-net weights for k_substeps (env_kernels.hip: one aligned record per hidden unit), built on the host
+#define LG_LSTM_REC 116
+#define LG_LSTM_LDS (4 + 8 * LG_LSTM_REC)
+// float o of the image, from the lg_cfg.lstm_w blob (the two bias vectors of a layer pre-added, as the kernel adds them first)
+static inline float lstm_lds_image(const float *__restrict__ w, int o) {
+    constexpr int WIH0 = 3, WHH0 = WIH0 + 64, BIH0 = WHH0 + 256, BHH0 = BIH0 + 32, WIH1 = BHH0 + 32, WHH1 = WIH1 + 256,
+                  BIH1 = WHH1 + 256, BHH1 = BIH1 + 32, LW = BHH1 + 32;
+    if (o < 4) return o < 3 ? w[o] : w[LG_LSTM_NW - 1];                    // in_scale 2, out_scale, lin_b
+    const int k = (o - 4) / LG_LSTM_REC, f = (o - 4) % LG_LSTM_REC;
+    if (f < 4) return w[BIH0 + f * 8 + k] + w[BHH0 + f * 8 + k];
+    if (f < 8) return w[BIH1 + (f - 4) * 8 + k] + w[BHH1 + (f - 4) * 8 + k];
+    if (f < 16) return w[WIH0 + (((f - 8) >> 1) * 8 + k) * 2 + ((f - 8) & 1)];
+    if (f < 48) return w[WHH0 + (((f - 16) >> 3) * 8 + k) * 8 + ((f - 16) & 7)];
+    if (f < 80) return w[WIH1 + (((f - 48) >> 3) * 8 + k) * 8 + ((f - 48) & 7)];
+    if (f < 112) return w[WHH1 + (((f - 80) >> 3) * 8 + k) * 8 + ((f - 80) & 7)];
+    return f == 112 ? w[LW + k] : 0.0f;
+}
+
 struct DevParams {
     lg_cfg cfg;          // host pointers inside are NOT valid on device (use the ones below)
     lg_model model;
@@ -39,6 +57,8 @@ struct DevParams {
     // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
     int n_leg_slots, n_base_spheres;
     int slot_link[LG_MAX_SPHERES];           // joint index within the chain (same for every leg)
+    unsigned long long slot_link_pk;
+    float lstm_img[LG_LSTM_LDS];         // the same, 4 bits per slot (one scalar load for the physics lanes)
     int slot_body[LG_MAX_SPHERES][4 + 4];    // [slot][leg] body row (legs <= 8)
     float slot_center[LG_MAX_SPHERES][8][3];
     float slot_radius[LG_MAX_SPHERES][8];

@@ -285,8 +285,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     unsigned amask = 0u;                       // bit si: slot si of this lane is in contact
     // sphere -> link table packed 4 bits per slot (wave-uniform scalar loads); the base slot maps to
     // link -1 = "no joint between the contact and the base"
-    unsigned long long link_pk = 0ull;
-    for (int s = 0; s < nslots; ++s) link_pk |= (unsigned long long)(P->slot_link[s] & 15) << (4 * s);
+    const unsigned long long link_pk = P->slot_link_pk;
     // (1) detection over every slot: geometry only
     const int nbase_it = (P->n_base_spheres + L - 1) / L;       // base spheres per lane this robot needs (wave-uniform)
     for (int s = 0; s < nslots + nbase_it; ++s) {
@@ -302,7 +301,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                 cbk = ld3(lt + LG_LT_BASE + 4 * ub);
                 rad = lt[LG_LT_BASE + 4 * ub + 3];
             } else {
-                const int jl = P->slot_link[s];
+                const int jl = (int)((link_pk >> (4 * s)) & 15ull);
                 M3 Rk;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) Rk.m[e / 3][e % 3] = LK(jl, e);
@@ -320,12 +319,13 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                 vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
             }
         }
-        CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
-        CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
-        CF(si, 12) = vtarget;
-        CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
-        CF(si, 16) = active ? 1.0f : 0.0f;
-        if (active) amask |= 1u << si;
+        if (active) {                                   // records of inactive slots are never read for a result
+            CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
+            CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
+            CF(si, 12) = vtarget;
+            CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
+            amask |= 1u << si;
+        }
     }
     // (2) W per ACTIVE slot: every lane walks its own list of set bits, so the trip count is the largest
     // number of simultaneous contacts of any lane of the wave, not the number of slots in contact

@@ -1,0 +1,546 @@
+// Pair-lane articulated-body physics for gfx950: TWO lanes per (environment, leg).
+//
+// Same algorithm, same LDS records and same results (up to fp32 summation order) as physics_lane in lg_physics.h; the
+// difference is the lane map.  The control loop is bound by the VALU issue rate of the one wave per CU that runs the
+// physics (profiles/r02_substeps_pmc.json), and most of that work is 6-vector / 6x6 arithmetic.  Here the two lanes of a
+// pair split every spatial quantity by rows: lane h = 0 holds the angular half (w rows), lane h = 1 the linear half
+// (v rows) of every spatial vector, and the matching three rows of every 6x6 matrix, stored as two 3x3 blocks relative to
+// the lane's own role:  mm multiplies the lane's own half of an operand, mo the partner's half.  With that convention a
+// 6x6 product, a rank-one update and a spatial dot product are role-free code:
+//      (I x).mine = mm * x.mine + mo * x.other          x.other = DPP quad_perm [1,0,3,2] of x.mine
+//      <a, b>     = dot3(a.mine, b.mine) + the partner's (one DPP add)
+// Only the spatial cross products and the rigid-body inertia need a role select.  3x3 kinematics, contact detection and
+// the scalar contact law run redundantly in both lanes (identical inputs, identical results), so every branch and trip
+// count stays uniform inside a pair.  Lanes of an environment: index = leg * 2 + h, i.e. 2L consecutive lanes; leg sums
+// are DPP butterflies over lane xor 2 (and xor 4 for L = 4).  A block's 64 (env, leg) pairs occupy waves 0 and 1, which
+// sit on different SIMDs of the CU and run concurrently.
+#pragma once
+#include "lg_physics.h"
+
+__device__ __forceinline__ float psum(float x) { return x + quad_xor1(x); }                  // sum over the pair
+__device__ __forceinline__ V3 px3(V3 a) { return {quad_xor1(a.x), quad_xor1(a.y), quad_xor1(a.z)}; }
+__device__ __forceinline__ V3 sel3(bool h, V3 a, V3 b) { return {h ? a.x : b.x, h ? a.y : b.y, h ? a.z : b.z}; }
+__device__ __forceinline__ float lane_xor4(float x) {
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141 /*row_half_mirror: i -> 7 - i*/, 0xF, 0xF, true);
+    t = __builtin_amdgcn_update_dpp(0, t, 0x1B /*quad_perm [3,2,1,0]: i -> i ^ 3*/, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, t);
+}
+template <int L>
+__device__ __forceinline__ float pleg_sum(float x) {     // sum over the L legs of one environment, same role
+    static_assert(L == 2 || L == 4, "2L lanes of an environment sit in one group of 4 or 8 lanes");
+    x += quad_xor2(x);
+    if (L == 4) x += lane_xor4(x);
+    return x;
+}
+template <int L>
+__device__ __forceinline__ V3 pleg_sum(V3 a) { return {pleg_sum<L>(a.x), pleg_sum<L>(a.y), pleg_sum<L>(a.z)}; }
+
+struct H6 { M3 mm, mo; };                                // this lane's three rows of a spatial 6x6
+__device__ __forceinline__ V3 hmul(const H6 &I, V3 xm, V3 xo) { return mul(I.mm, xm) + mul(I.mo, xo); }
+__device__ __forceinline__ V3 hmul(const H6 &I, V3 xm) { return hmul(I, xm, px3(xm)); }
+__device__ __forceinline__ float pdot(V3 a, V3 b) { return psum(dot(a, b)); }
+// rows of the rigid-body inertia [[Ic + m(cc 1 - c c^T), m cx], [m cx^T, m 1]] about the frame origin
+__device__ __forceinline__ H6 rigid_inertia_h(bool h, float m, V3 c, const M3 &Ic) {
+    H6 I;
+    const float cc = dot(c, c), sm = h ? -m : m;
+    const float cv[3] = {c.x, c.y, c.z};
+    const float hx[3][3] = {{0.f, -sm * c.z, sm * c.y}, {sm * c.z, 0.f, -sm * c.x}, {-sm * c.y, sm * c.x, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float top = Ic.m[i][j] + m * ((i == j ? cc : 0.0f) - cv[i] * cv[j]);
+            const float bot = (i == j) ? m : 0.0f;
+            I.mm.m[i][j] = h ? bot : top;
+            I.mo.m[i][j] = hx[i][j];
+        }
+    return I;
+}
+// my half of crf(a, f) = {a.w x f.w + a.v x f.v, a.w x f.v}
+__device__ __forceinline__ V3 crf_h(bool h, V3 am, V3 ao, V3 fm, V3 fo) {
+    const V3 t = cross(sel3(h, ao, am), fm);             // a.w x f.mine in both roles
+    const V3 t2 = cross(ao, fo);                         // role 0: a.v x f.v
+    return {t.x + (h ? 0.f : t2.x), t.y + (h ? 0.f : t2.y), t.z + (h ? 0.f : t2.z)};
+}
+// my half of crm(a, b) = {a.w x b.w, a.w x b.v + a.v x b.w}
+__device__ __forceinline__ V3 crm_h(bool h, V3 am, V3 ao, V3 bm, V3 bo) {
+    const V3 t = cross(sel3(h, ao, am), bm);             // a.w x b.mine
+    const V3 t2 = cross(am, bo);                         // role 1: a.v x b.w
+    return {t.x + (h ? t2.x : 0.f), t.y + (h ? t2.y : 0.f), t.z + (h ? t2.z : 0.f)};
+}
+
+// Inverse of the SPD 6x6 whose rows are spread over the pair; returns this lane's rows of the inverse in H6 form.
+// Each lane gathers the matrix in ITS OWN block order [mine, other] (a symmetric permutation of the other lane's), factors
+// it and solves for the first three columns only: by symmetry these are the lane's rows, already split as [mm | mo].
+// One instruction stream, no role selects; the two lanes' halves come from differently ordered factorisations of the same
+// matrix and agree to rounding.
+__device__ __forceinline__ bool spd_inverse_h(const H6 &A, H6 &Ainv) {
+    float a[6][6];                                       // lower triangle only
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[k][j] = A.mm.m[k][j];
+            a[3 + k][j] = quad_xor1(A.mo.m[k][j]);       // partner's rows, the columns of my half
+            a[3 + k][3 + j] = quad_xor1(A.mm.m[k][j]);
+        }
+    float Lm[6][6], Li[6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = a[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
+            if (i == j) { ok = ok && (s > 0.0f); Li[i] = rsqrtf(fmaxf(s, 1e-30f)); Lm[i][i] = s * Li[i]; }
+            else Lm[i][j] = s * Li[j];
+        }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float y[6], x[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float s = (i == r) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = r; k < i; ++k) s -= Lm[i][k] * y[k];
+            y[i] = (i < r) ? 0.f : s * Li[i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            float s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) s -= Lm[k][i] * x[k];
+            x[i] = s * Li[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { Ainv.mm.m[r][j] = x[j]; Ainv.mo.m[r][j] = x[3 + j]; }
+    }
+    const float okf = ok ? 1.0f : 0.0f;
+    return fminf(okf, quad_xor1(okf)) > 0.5f;            // uniform over the pair
+}
+
+// Section timing of the control loop (tools/substeps_sections.py): built only with -DLG_PROF_SUBSTEPS into a separate
+// library; s_memtime deltas accumulated per section in SGPRs.
+#ifdef LG_PROF_SUBSTEPS
+struct SubProf { unsigned long long acc[16], last; };
+#define PSTAMP(pr, k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (pr).acc[k] += t_ - (pr).last; (pr).last = t_; } while (0)
+#else
+struct SubProf {};
+#define PSTAMP(pr, k) do { } while (0)
+#endif
+
+#define LG_LKP_NF 12     // floats per link record shared by the pair: R 9, p 3
+#define LG_LKH_NF 6      // floats per link record per lane: my half of vel 3, of the velocity-product term 3
+
+// One physics step of length dt for lane (env, leg, h).  root, q, qd, tau, friction, dmass are replicated in both lanes
+// of the pair and come back identical.  pcol = column of the pair (0..63) in the contact / limit / shared link records,
+// lcol = column of the lane (0..127) in the per-lane link records.
+template <int L, int J>
+__device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, int leg, bool h, int pcol, int lcol, float dt,
+                                             float *root, float *q, float *qd, const float *tau, float friction, float dmass,
+                                             V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkp,
+                                             float *__restrict__ lkh, const float *__restrict__ ltab, float *__restrict__ lmt,
+                                             SubProf &pr) {
+    const lg_cfg &c = P->cfg;
+    const lg_model &m = P->model;
+    const float *__restrict__ lt = ltab + leg * LG_LT_STRIDE;
+    const M3 Rb = quat_to_mat(root + 3);
+    const V3 xw = {root[0], root[1], root[2]};
+    const V3 vb = mulT(Rb, V3{root[7], root[8], root[9]}), wb = mulT(Rb, V3{root[10], root[11], root[12]});
+    const V3 gb = mulT(Rb, V3{c.gravity[0], c.gravity[1], c.gravity[2]});
+    const V3 vel0 = sel3(h, vb, wb), vel0o = sel3(h, wb, vb);
+    const V3 zero3 = {0.f, 0.f, 0.f};
+
+#define LKP(j, f) lkp[((j) * LG_LKP_NF + (f)) * 64 + pcol]
+#define LKH(j, f) lkh[((j) * LG_LKH_NF + (f)) * 128 + lcol]
+    V3 S[J], U[J];                                       // my halves
+    float iD[J], u[J];
+    const float inv_dt = frcp(dt);
+    {   // outward kinematics (3x3 part in both lanes, spatial part by halves)
+        M3 Rpar = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
+        V3 ppar = {0.f, 0.f, 0.f};
+        V3 vpar = vel0, vparo = vel0o;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float *jt = lt + LG_LT_JOINT * j;
+            M3 Rj = mul(Rpar, load3(jt));
+            V3 ax = ld3(jt + 12);
+            V3 pj = ppar + mul(Rpar, ld3(jt + 9));
+            V3 axb = mul(Rj, ax);
+            M3 Rlj = mul(Rj, rodrigues(ax, q[j]));
+            const V3 Sw = axb, Sv_ = cross(pj, axb);
+            S[j] = sel3(h, Sv_, Sw);
+            const V3 So = sel3(h, Sw, Sv_);
+            const V3 vj = qd[j] * S[j], vjo = qd[j] * So;
+            const V3 velj = vpar + vj, veljo = vparo + vjo;
+            const V3 cbj = crm_h(h, velj, veljo, vj, vjo);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) LKP(j, e) = Rlj.m[e / 3][e % 3];
+            LKP(j, 9) = pj.x; LKP(j, 10) = pj.y; LKP(j, 11) = pj.z;
+            LKH(j, 0) = velj.x; LKH(j, 1) = velj.y; LKH(j, 2) = velj.z;
+            LKH(j, 3) = cbj.x; LKH(j, 4) = cbj.y; LKH(j, 5) = cbj.z;
+            Rpar = Rlj; ppar = pj; vpar = velj; vparo = veljo;
+        }
+    }
+    PSTAMP(pr, 2);
+    // inward pass along the chain
+    H6 Ia_run;
+    V3 pa_run = zero3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { Ia_run.mm.m[a][b] = 0.f; Ia_run.mo.m[a][b] = 0.f; }
+#pragma unroll
+    for (int j = J - 1; j >= 0; --j) {
+        const float *jt = lt + LG_LT_JOINT * j;
+        M3 Rlj;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Rlj.m[e / 3][e % 3] = LKP(j, e);
+        const V3 pj = {LKP(j, 9), LKP(j, 10), LKP(j, 11)};
+        const V3 velj = {LKH(j, 0), LKH(j, 1), LKH(j, 2)};
+        const V3 cbj = {LKH(j, 3), LKH(j, 4), LKH(j, 5)};
+        const V3 veljo = px3(velj);
+        M3 Ic = mulBT(mul(Rlj, load3(jt + 15)), Rlj);
+        H6 IA = rigid_inertia_h(h, jt[27], pj + mul(Rlj, ld3(jt + 24)), Ic);
+        const V3 Iv = hmul(IA, velj, veljo);
+        V3 pA = crf_h(h, velj, veljo, Iv, px3(Iv));
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { IA.mm.m[a][b] += Ia_run.mm.m[a][b]; IA.mo.m[a][b] += Ia_run.mo.m[a][b]; }
+        pA = pA + pa_run;
+        U[j] = hmul(IA, S[j]);
+        const float Dj = pdot(S[j], U[j]);
+        u[j] = (tau[j] - jt[28] * qd[j]) - pdot(S[j], pA);
+        const float invD = frcp(Dj);
+        iD[j] = invD;
+        const V3 Uo = px3(U[j]);
+        const float Um[3] = {U[j].x, U[j].y, U[j].z}, Uov[3] = {Uo.x, Uo.y, Uo.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float ua = Um[a] * invD;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                Ia_run.mm.m[a][b] = IA.mm.m[a][b] - ua * Um[b];
+                Ia_run.mo.m[a][b] = IA.mo.m[a][b] - ua * Uov[b];
+            }
+        }
+        pa_run = pA + hmul(Ia_run, cbj) + (u[j] * invD) * U[j];
+    }
+    PSTAMP(pr, 3);
+    // floating base
+    H6 I0 = rigid_inertia_h(h, m.mass[0] + dmass, ld3(m.com[0]), load3(m.inertia[0]));
+    const V3 I0v = hmul(I0, vel0, vel0o);
+    const V3 pA0 = crf_h(h, vel0, vel0o, I0v, px3(I0v)) + pleg_sum<L>(pa_run);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            I0.mm.m[a][b] += pleg_sum<L>(Ia_run.mm.m[a][b]);
+            I0.mo.m[a][b] += pleg_sum<L>(Ia_run.mo.m[a][b]);
+        }
+    H6 I0inv;
+    const bool ok = spd_inverse_h(I0, I0inv);
+    const V3 a0 = -1.0f * hmul(I0inv, pA0);
+    PSTAMP(pr, 4);
+    // outward accelerations -> free velocities
+    V3 velf[J], velf0;
+    float qdf[J];
+    {
+        const V3 grav = sel3(h, gb, zero3);
+        velf0 = vel0 + dt * (a0 + grav);
+        V3 apar = a0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const V3 velj = {LKH(j, 0), LKH(j, 1), LKH(j, 2)};
+            const V3 cbj = {LKH(j, 3), LKH(j, 4), LKH(j, 5)};
+            V3 ap = apar + cbj;
+            float qdd = (u[j] - pdot(U[j], ap)) * iD[j];
+            V3 acc = ap + qdd * S[j];
+            velf[j] = velj + dt * (acc + grav);
+            qdf[j] = qd[j] + dt * qdd;
+            apar = acc;
+        }
+    }
+
+    PSTAMP(pr, 5);
+    // ---- contact detection + W per slot.  The records are shared by the pair: both lanes compute and store the same
+    // values to the same column (each lane reads back what it wrote itself; no cross-lane ordering is relied on).
+    const float mu = 0.5f * (friction + c.ground_friction);
+    const int nslots = P->n_leg_slots;
+#define CF(si, f) cst[((si) * LG_CT_NF + (f)) * 64 + pcol]
+    unsigned amask = 0u;
+    const unsigned long long link_pk = P->slot_link_pk;
+    const int nbase_it = (P->n_base_spheres + L - 1) / L;
+    for (int s = 0; s < nslots + nbase_it; ++s) {
+        const bool is_base = s >= nslots;
+        const int ub = s - nslots;
+        const int si = is_base ? LG_MAX_LEG_SLOTS + ub : s;
+        const bool exists = is_base ? (leg + ub * L < P->n_base_spheres) : true;
+        V3 cbk = {0.f, 0.f, 0.f}, Pc = {0.f, 0.f, 0.f}, nb = {0.f, 0.f, 1.f};
+        float rad = 0.f, vtarget = 0.f;
+        bool active = false;
+        if (exists) {
+            if (is_base) {
+                cbk = ld3(lt + LG_LT_BASE + 4 * ub);
+                rad = lt[LG_LT_BASE + 4 * ub + 3];
+            } else {
+                const int jl = (int)((link_pk >> (4 * s)) & 15ull);
+                M3 Rk;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) Rk.m[e / 3][e % 3] = LKP(jl, e);
+                const V3 pk = {LKP(jl, 9), LKP(jl, 10), LKP(jl, 11)};
+                cbk = pk + mul(Rk, ld3(lt + LG_LT_SLOTS + 4 * s));
+                rad = lt[LG_LT_SLOTS + 4 * s + 3];
+            }
+            V3 cw = xw + mul(Rb, cbk);
+            Ground g = ground_at(P, cw.x, cw.y);
+            float gap = (cw.z - g.h) * g.n.z - rad;
+            if (gap < c.contact_offset) {
+                active = true;
+                nb = mulT(Rb, g.n);
+                Pc = cbk - rad * nb;
+                vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+            }
+        }
+        if (active) {                                   // records of inactive slots are never read for a result
+            CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
+            CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
+            CF(si, 12) = vtarget;
+            CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
+            amask |= 1u << si;
+        }
+    }
+    PSTAMP(pr, 6);
+    for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
+        const bool valid = rem != 0u;
+        const int si = valid ? __ffs(rem) - 1 : 0;
+        const int jl = (si >= LG_MAX_LEG_SLOTS) ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
+        const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
+        V3 t1, t2;
+        tangents(nb, t1, t2);
+        V3 dirs[3] = {nb, t1, t2};
+        float Wc[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            V3 pAi = -1.0f * sel3(h, dirs[a], cross(Pc, dirs[a]));
+            float ui[J];
+#pragma unroll
+            for (int k = J - 1; k >= 0; --k) {
+                if (k <= jl) {
+                    ui[k] = -pdot(S[k], pAi);
+                    pAi = pAi + (ui[k] * iD[k]) * U[k];
+                } else ui[k] = 0.f;
+            }
+            V3 dv = -1.0f * hmul(I0inv, pAi);
+#pragma unroll
+            for (int k = 0; k < J; ++k)
+                if (k <= jl) {
+                    float dq = (ui[k] - pdot(U[k], dv)) * iD[k];
+                    dv = dv + dq * S[k];
+                }
+            const V3 part = sel3(h, dv, cross(dv, Pc));      // dv.v | dv.w x Pc
+            const V3 dvP = part + px3(part);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
+        }
+        if (valid) {
+            CF(si, 6) = Wc[0][0] > 1e-9f ? frcp(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
+            CF(si, 9) = Wc[1][1] > 1e-9f ? frcp(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
+            CF(si, 11) = Wc[2][2] > 1e-9f ? frcp(Wc[2][2]) : 0.f;
+        }
+    }
+    const int n_base_active = (int)pleg_sum<L>((float)__popc(amask >> LG_MAX_LEG_SLOTS));
+    const int n_leg_active = __popc(amask & ((1u << LG_MAX_LEG_SLOTS) - 1u));
+    const float rl = frcp((float)max(n_leg_active, 1)), rb = frcp((float)max(n_base_active, 1));
+
+    PSTAMP(pr, 7);
+    // ---- joint position limits
+#define LM(j, f) lmt[((j) * 4 + (f)) * 64 + pcol]
+    unsigned lmask = 0u;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+        float sgn = 0.f, gap = 0.f;
+        if (hi > lo) {
+            const float qn = q[j] + dt * qdf[j];
+            if (qn > hi) { sgn = 1.0f; gap = hi - q[j]; }
+            else if (qn < lo) { sgn = -1.0f; gap = q[j] - lo; }
+        }
+        const bool act = sgn != 0.f;
+        if (!__any(act)) continue;
+        V3 pAi = zero3;
+        float ui[J];
+#pragma unroll
+        for (int k = J - 1; k >= 0; --k) {
+            if (k > j) ui[k] = 0.f;
+            else {
+                ui[k] = (k == j ? 1.0f : 0.f) - pdot(S[k], pAi);
+                pAi = pAi + (ui[k] * iD[k]) * U[k];
+            }
+        }
+        V3 dv = -1.0f * hmul(I0inv, pAi);
+        float Wj = 0.f;
+#pragma unroll
+        for (int k = 0; k < J; ++k)
+            if (k <= j) {
+                const float dq = (ui[k] - pdot(U[k], dv)) * iD[k];
+                dv = dv + dq * S[k];
+                if (k == j) Wj = dq;
+            }
+        if (act) {
+            lmask |= 1u << j;
+            LM(j, 0) = sgn;
+            LM(j, 1) = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+            LM(j, 2) = Wj > 1e-9f ? frcp(Wj) : 0.f;
+            LM(j, 3) = 0.f;
+        }
+    }
+    const float rlim = frcp((float)max(__popc(lmask), 1));
+
+    PSTAMP(pr, 8);
+    // ---- projected Jacobi sweeps
+    if (__any((amask | lmask) != 0u)) {
+        for (int it = 0; it < c.solver_iterations; ++it) {
+            V3 fimp[J], fb = zero3;
+#pragma unroll
+            for (int k = 0; k < J; ++k) fimp[k] = zero3;
+            for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
+                const bool active = rem != 0u;
+                const int si = active ? __ffs(rem) - 1 : 0;
+                const bool is_base = si >= LG_MAX_LEG_SLOTS;
+                const int jl = is_base ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
+                V3 vl = velf0;
+#pragma unroll
+                for (int k = 0; k < J; ++k)
+                    if (jl == k) vl = velf[k];
+                // the point velocity needs both halves: executed by every lane (DPP under a divergent branch would read
+                // disabled partners), the contact law below only where this pair still has a contact to visit
+                const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
+                const V3 part = sel3(h, vl, cross(vl, Pc));
+                const V3 vP = part + px3(part);
+                if (active) {
+                    const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
+                    V3 t1, t2;
+                    tangents(nb, t1, t2);
+                    float vc0 = dot(nb, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
+                    float ln = fmaxf(0.0f, oln - relax * (vc0 - CF(si, 12)) * CF(si, 6));
+                    float dn = ln - oln;
+                    vc1 += CF(si, 7) * dn;
+                    vc2 += CF(si, 8) * dn;
+                    float l1 = ol1 - relax * vc1 * CF(si, 9);
+                    vc2 += CF(si, 10) * (l1 - ol1);
+                    float l2 = ol2 - relax * vc2 * CF(si, 11);
+                    float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
+                    if (mag > lim) { float sc = lim * frcp(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
+                    V3 dl = (ln - oln) * nb + (l1 - ol1) * t1 + (l2 - ol2) * t2;
+                    CF(si, 13) = ln; CF(si, 14) = l1; CF(si, 15) = l2;
+                    const V3 f = sel3(h, dl, cross(Pc, dl));
+                    if (is_base) fb = fb + f;
+#pragma unroll
+                    for (int k = 0; k < J; ++k)
+                        if (jl == k) fimp[k] = fimp[k] + f;
+                }
+            }
+            float ui[J], timp[J];
+#pragma unroll
+            for (int k = 0; k < J; ++k) {
+                timp[k] = 0.f;
+                if ((lmask >> k) & 1u) {
+                    const float sgn = LM(k, 0), old = LM(k, 3);
+                    const float ln = fmaxf(0.0f, old - rlim * (-sgn * qdf[k] - LM(k, 1)) * LM(k, 2));
+                    timp[k] = -sgn * (ln - old);
+                    LM(k, 3) = ln;
+                }
+            }
+            V3 run = zero3;
+#pragma unroll
+            for (int k = J - 1; k >= 0; --k) {
+                V3 cur = run - fimp[k];
+                ui[k] = timp[k] - pdot(S[k], cur);
+                run = cur + (ui[k] * iD[k]) * U[k];
+            }
+            V3 pAi0 = pleg_sum<L>(run - fb);
+            V3 dv = -1.0f * hmul(I0inv, pAi0);
+            velf0 = velf0 + dv;
+#pragma unroll
+            for (int k = 0; k < J; ++k) {
+                float dq = (ui[k] - pdot(U[k], dv)) * iD[k];
+                dv = dv + dq * S[k];
+                velf[k] = velf[k] + dv;
+                qdf[k] += dq;
+            }
+        }
+    }
+
+    PSTAMP(pr, 9);
+    // ---- contact forces out (world frame, N)
+    fbase = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int si = 0; si < LG_NUM_SLOTS; ++si) {
+        V3 f = {0.f, 0.f, 0.f};
+        if ((amask >> si) & 1u) {
+            const V3 nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
+            V3 t1, t2;
+            tangents(nb, t1, t2);
+            f = inv_dt * mul(Rb, CF(si, 13) * nb + CF(si, 14) * t1 + CF(si, 15) * t2);
+        }
+        if (si >= LG_MAX_LEG_SLOTS) fbase = fbase + f; else fslot[si] = f;
+    }
+#undef CF
+#undef LKP
+#undef LKH
+#undef LM
+    // ---- fault guard
+    float chk = pdot(velf0, velf0);
+#pragma unroll
+    for (int j = 0; j < J; ++j) chk += qdf[j] * qdf[j] * 1e-4f;
+    chk = pleg_sum<L>(chk);
+    if (!ok || !(chk < 2.0e4f)) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) qd[j] = 0.f;
+#pragma unroll
+        for (int k = 7; k < 13; ++k) root[k] = 0.f;
+        return true;
+    }
+    PSTAMP(pr, 10);
+    // ---- integrate (both lanes, identical)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float v = qdf[j];
+        {
+            const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+            if (hi > lo) {
+                const float qn = fminf(fmaxf(q[j] + dt * v, fminf(lo, q[j])), fmaxf(hi, q[j]));
+                v = (qn - q[j]) * inv_dt;
+            }
+        }
+        float vl = lt[LG_LT_JOINT * j + 29];
+        if (vl > 0.0f) v = fminf(fmaxf(v, -vl), vl);
+        qd[j] = v;
+        q[j] += dt * v;
+    }
+    const V3 velf0o = px3(velf0);
+    V3 wn = sel3(h, velf0o, velf0);
+    V3 vn = sel3(h, velf0, velf0o) + dt * cross(wb, vb);
+    V3 vw = mul(Rb, vn), ww = mul(Rb, wn);
+    root[0] += dt * vw.x; root[1] += dt * vw.y; root[2] += dt * vw.z;
+    root[7] = vw.x; root[8] = vw.y; root[9] = vw.z;
+    root[10] = ww.x; root[11] = ww.y; root[12] = ww.z;
+    float ang = sqrtf(dot(wn, wn)) * dt;
+    float sh, ch = cosf(0.5f * ang);
+    V3 ax;
+    if (ang > 1e-8f) { sh = sinf(0.5f * ang); ax = (dt / ang) * wn; } else { sh = 0.5f * dt; ax = wn; }
+    float dq[4] = {sh * ax.x, sh * ax.y, sh * ax.z, ch};
+    float *qq = root + 3;
+    float qn[4] = {qq[3] * dq[0] + qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1],
+                   qq[3] * dq[1] - qq[0] * dq[2] + qq[1] * dq[3] + qq[2] * dq[0],
+                   qq[3] * dq[2] + qq[0] * dq[1] - qq[1] * dq[0] + qq[2] * dq[3],
+                   qq[3] * dq[3] - qq[0] * dq[0] - qq[1] * dq[1] - qq[2] * dq[2]};
+    float nrm = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qq[k] = qn[k] * nrm;
+    PSTAMP(pr, 11);
+    return false;
+}
