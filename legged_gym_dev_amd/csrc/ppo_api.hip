@@ -26,7 +26,8 @@ void ppok_adv_normalize(const PpoDev *P, hipStream_t s);
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s);
 void ppok_randperm(const PpoDev *P, int n, uint64_t update_idx, hipStream_t s);
 void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, float *dval, hipStream_t s);
-void ppok_step(const PpoDev *P, int par, hipStream_t s);
+int ppok_step(const PpoDev *P, int par, const PpoDev *G, int gather_mb, hipStream_t s);
+size_t ppok_head_part_floats();
 int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
                     int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c, hipStream_t s);
 }
@@ -68,6 +69,11 @@ struct lg_ppo {
     int Mmax;
     std::vector<void *> allocs;
     int64_t perm_count;                      // updates begun: keys the device-side minibatch permutation
+    // minibatch gathers are double-buffered: the optimiser step of minibatch mb gathers mb + 1 into the other set in the spare
+    // workgroups of its norm-reduction launch (the gather depends on the rollout storage and the permutation only)
+    struct MbSet { float *obs, *critic_obs, *actions, *mu, *scalars; } mbset[2];
+    int mb_cur, mb_ready, mb_last;           // set the kernels read now; minibatch held by the other set (-1: none); last backward
+    int gather_ahead;
     lg_ppo_buffers pub;
 };
 
@@ -165,8 +171,12 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         if (splits > max_splits) splits = max_splits;
         if (splits >= 8) splits &= ~7;                 // whole groups of 8 slices: one per XCD (xcd_tile)
         if (splits < 1) splits = 1;
-        hipStream_t dw_stream = p->overlap ? p->side : p->stream;
-        if (p->overlap) {                            // dz[l+1] is complete on the main stream at this point
+        // the weight gradient of layer l runs beside the input-gradient chain on the side stream -- except the last one
+        // (l = 0), which has nothing left to overlap with: on the main stream it starts without the cross-stream event wait
+        static const int dw0_main = getenv("LG_DW0_MAIN") ? atoi(getenv("LG_DW0_MAIN")) : 1;
+        const bool on_side = p->overlap && (l > 0 || !dw0_main);
+        hipStream_t dw_stream = on_side ? p->side : p->stream;
+        if (on_side) {                               // dz[l+1] is complete on the main stream at this point
             (void)hipEventRecord(p->ev_dz, p->stream);
             (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
         }
@@ -305,9 +315,17 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     PA(d.st_log_prob, TN); PA(d.st_mu, TN * A); PA(d.st_sigma, A); PA(d.st_dones, TN);
     PA(d.act_actions, (size_t)N * A); PA(d.act_values, N); PA(d.act_log_prob, N); PA(d.act_mu, (size_t)N * A);
     PA(d.stats, 8); PA(d.loss_acc, 4); PA(d.noise, (size_t)N * A); PA(d.perm, TN); PA(d.adv_partial, 4);
-    PA(d.mb_obs, (size_t)R * O);
-    if (cfg->num_critic_obs > 0) PA(d.mb_critic_obs, (size_t)R * OC); else d.mb_critic_obs = d.mb_obs;
-    PA(d.mb_actions, (size_t)R * A); PA(d.mb_mu, (size_t)R * A); PA(d.mb_scalars, (size_t)R * 4);
+    for (int k = 0; k < 2; ++k) {
+        lg_ppo::MbSet &m = p->mbset[k];
+        PA(m.obs, (size_t)R * O);
+        if (cfg->num_critic_obs > 0) PA(m.critic_obs, (size_t)R * OC); else m.critic_obs = m.obs;
+        PA(m.actions, (size_t)R * A); PA(m.mu, (size_t)R * A); PA(m.scalars, (size_t)R * 4);
+    }
+    p->mb_cur = 0; p->mb_ready = -1; p->mb_last = -1;
+    p->gather_ahead = getenv("LG_GATHER_AHEAD") ? atoi(getenv("LG_GATHER_AHEAD")) : 1;
+    d.mb_obs = p->mbset[0].obs; d.mb_critic_obs = p->mbset[0].critic_obs; d.mb_actions = p->mbset[0].actions;
+    d.mb_mu = p->mbset[0].mu; d.mb_scalars = p->mbset[0].scalars;
+    PA(d.head_part, ppok_head_part_floats());
     PA(d.cur_reward_sum, N); PA(d.cur_episode_len, N); PA(d.ep_stats, 4); PA(d.ep_ring, 200); PA(d.ep_ring_count, 1);
     for (int z = 0; z < 2; ++z) {
         Net &n = p->net[z];
@@ -380,7 +398,12 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
         }
         if (same) fused = ppok_mlp_fwd(&g, 3, p->stream);
     }
-    if (fused != 0) forward(p, p->cfg.num_envs, obs, cobs, 3);
+    if (fused != 0) {
+        // per-layer GEMMs on the optimiser's weight planes (no re-split of W per tile); same freshness rule as above
+        static const int act_planes = getenv("LG_ACT_PLANES") ? atoi(getenv("LG_ACT_PLANES")) : 1;
+        if (act_planes && !p->fused_act && p->step == 0) ppok_sync_planes(&p->dev, p->stream);
+        forward(p, p->cfg.num_envs, obs, cobs, 3, 0, act_planes != 0);
+    }
     ppok_act_sample(&p->dev, obs, cobs, p->net[0].act[p->net[0].nl], p->net[1].act[p->net[1].nl], p->step, p->act_count,
                     p->inject, p->stream);
     p->act_count++;
@@ -409,6 +432,7 @@ int lg_ppo_begin_update(lg_ppo *p) {
     // randperm(num_mini_batches * mini_batch_size), drawn once per update and reused by every epoch (Appendix B): on the device
     const size_t n = (size_t)p->dev.mb_rows * p->cfg.num_mini_batches;
     ppok_randperm(&p->dev, (int)n, (uint64_t)p->perm_count++, p->stream);
+    p->mb_ready = -1;                           // a set gathered ahead belongs to the previous permutation
     (void)hipMemsetAsync(p->dev.stats + 2, 0, 2 * sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.stats + 5, 0, sizeof(float), p->stream);
     (void)hipMemsetAsync(p->dev.loss_acc, 0, 4 * sizeof(float), p->stream);
@@ -424,7 +448,18 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     // k_opt_adam leaves the gradient buffer zeroed; only a backward pass that was never stepped needs a clear
     if (p->grads_dirty) (void)hipMemsetAsync(d.grads, 0, (size_t)(d.num_params + 2) * sizeof(float), p->stream);
     p->grads_dirty = 1;
-    ppok_gather(&d, mb, p->stream);
+    auto use_set = [&](PpoDev &dev, int k) {
+        const lg_ppo::MbSet &m = p->mbset[k];
+        dev.mb_obs = m.obs; dev.mb_critic_obs = m.critic_obs; dev.mb_actions = m.actions; dev.mb_mu = m.mu; dev.mb_scalars = m.scalars;
+    };
+    if (p->mb_ready == mb) {                                    // gathered ahead by the previous optimiser step
+        p->mb_cur ^= 1;
+        use_set(d, p->mb_cur);
+    } else {
+        ppok_gather(&d, mb, p->stream);
+    }
+    p->mb_ready = -1;
+    p->mb_last = mb;
     Net &na = p->net[0], &nc = p->net[1];
     const int nl = na.nl, H3 = na.dims[nl - 1];
     // fused head (forward + loss + backward of the two thin head layers) when both nets end in the same
@@ -447,7 +482,16 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
 }
 
 int lg_ppo_minibatch_step(lg_ppo *p) {
-    ppok_step(&p->dev, (int)(p->update_count & 1), p->stream);
+    int next = -1;
+    PpoDev other = p->dev;
+    if (p->gather_ahead && p->cfg.num_mini_batches > 1 && p->mb_last >= 0) {
+        // the next minibatch of the generator's order (the permutation is fixed for the whole update)
+        next = (p->mb_last + 1) % p->cfg.num_mini_batches;
+        const lg_ppo::MbSet &m = p->mbset[p->mb_cur ^ 1];
+        other.mb_obs = m.obs; other.mb_critic_obs = m.critic_obs; other.mb_actions = m.actions; other.mb_mu = m.mu; other.mb_scalars = m.scalars;
+    }
+    if (ppok_step(&p->dev, (int)(p->update_count & 1), &other, next, p->stream)) p->mb_ready = next;
+    p->mb_last = -1;
     p->grads_dirty = 0;
     p->update_count++;
     return launch_ok();

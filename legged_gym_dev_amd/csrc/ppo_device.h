@@ -36,7 +36,7 @@ struct PpoDev {                    // passed by value to kernels
     float *mb_obs, *mb_critic_obs, *mb_actions, *mb_mu, *mb_scalars;   // minibatch gathers; scalars = [v_old, ret, adv, logp_old]
     float *cur_reward_sum, *cur_episode_len, *ep_stats, *ep_ring;      // ep_ring (2, 100): last finished episodes' return / length
     int32_t *ep_ring_count;
-    float *dummy_pad_;                // per-env running sums; [sum_rew, sum_len, count] of finished episodes
+    float *head_part;              // scratch rows of k_head_net (one per workgroup), folded by k_head_finish
     // split-bf16 image of the weight matrices W [n][k], maintained by the optimiser step: three planes (h, m, l)
     // pl_stride elements apart; segment s = one weight matrix (rows x cols at flat offset seg_off)
     uint16_t *wpl;

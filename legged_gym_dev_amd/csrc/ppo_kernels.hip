@@ -368,7 +368,7 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char *p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)p);
 }
 
-template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false, int B_PL = 0>
+template <bool A_RC, bool B_RC, int TM, int TN, int WGM, int WGN, bool VEC, bool FULL = false, int B_PL = 0, bool LDB = false>
 __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int m0, int n0,
                                                  int M, int N, int k_begin, int k_end, unsigned char *__restrict__ lds, int wm, int wn, int li,
                                                  int lk, f32x16 (&acc)[TM][TN], const uint16_t *__restrict__ Bpl = nullptr,
@@ -376,27 +376,36 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
     constexpr int APL = x6_plane_bytes<BM>(), BPL = B_PL == 2 ? plt_plane_bytes<BN>() : x6_plane_bytes<BN>();
     constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;
-    // two register sets: the global loads of k-tile t+2 are issued before the MFMAs of tile t, and tile
-    // t+1 (already landed) is split and stored after them -- one full iteration to cover the L2/HBM latency
+    // two register sets: the global loads of k-tile t+2 are issued before the MFMAs of tile t, and tile t+1 (already
+    // landed) is split and stored after them -- one full iteration to cover the L2/HBM latency.
+    // LDB: two LDS stages.  With one stage an iteration is MFMAs | barrier | split + store | barrier, every wave in lock
+    // step, so the matrix pipe idles while the VALU splits and vice versa; that is hidden when a SIMD holds waves of
+    // several workgroups (the 128-row update configurations: 4 per SIMD) but not in the 64x64 configuration of the
+    // rollout forward (tools/gemm_small_bench.py: 0.70 us per k-tile with the machine otherwise idle).  With two stages
+    // the split + store of tile t+1 goes to the other stage with no barrier before it and overlaps the MFMAs of tile t.
+    constexpr int PD = 2;
     constexpr int NVP = B_PL ? BN * 12 / NT : 1;                 // 16-byte chunks of a plane k-tile per thread (either plane layout)
-    float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
-    uint4 pb0[NVP], pb1[NVP];
-    unsigned ma0, mb0, ma1 = 0, mb1 = 0;
+    struct Regs { float4 a[NVA], b[NVB]; uint4 p[NVP]; unsigned ma = 0, mb = 0; };
+    Regs R[PD];
     unsigned char *lds_b = lds + 3 * APL;
-    stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin, M, k_end, ra0, ma0);
-    if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, pb0, mb0);
-    else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, pb0, mb0);
-    else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin, N, k_end, rb0, mb0);
-    if (k_begin + BK < k_end) {
-        stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin + BK, M, k_end, ra1, ma1);
-        if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin + BK, N, k_end, pb1, mb1);
-        else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin + BK, N, k_end, pb1, mb1);
-        else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k_begin + BK, N, k_end, rb1, mb1);
-    }
-    stage_store_x6<A_RC, BM, NT, FULL>(lds, ra0, ma0);
-    if constexpr (B_PL == 2) stage_store_plt<BN, NT>(lds_b, pb0, mb0);
-    else if constexpr (B_PL == 1) stage_store_pl<BN, NT>(lds_b, pb0, mb0);
-    else stage_store_x6<B_RC, BN, NT, FULL>(lds_b, rb0, mb0);
+    auto load_tile = [&](Regs &r, int k) {
+        stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k, M, k_end, r.a, r.ma);
+        if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k, N, k_end, r.p, r.mb);
+        else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k, N, k_end, r.p, r.mb);
+        else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k, N, k_end, r.b, r.mb);
+    };
+    constexpr int STAGE = 3 * APL + 3 * BPL;                     // bytes of one LDS stage
+    auto store_tile = [&](Regs &r, int st) {
+        stage_store_x6<A_RC, BM, NT, FULL>(lds + st * STAGE, r.a, r.ma);
+        if constexpr (B_PL == 2) stage_store_plt<BN, NT>(lds_b + st * STAGE, r.p, r.mb);
+        else if constexpr (B_PL == 1) stage_store_pl<BN, NT>(lds_b + st * STAGE, r.p, r.mb);
+        else stage_store_x6<B_RC, BN, NT, FULL>(lds_b + st * STAGE, r.b, r.mb);
+    };
+    load_tile(R[0], k_begin);
+#pragma unroll
+    for (int d = 1; d < PD; ++d)
+        if (k_begin + d * BK < k_end) load_tile(R[d], k_begin + d * BK);
+    store_tile(R[0], 0);
     __syncthreads();
     // fragment of tile a, plane p, k-step s: base + a*8*X6_ROWB (32 logical rows = 8 physical) + p*PL + s*32
     const unsigned char *fa = lds + x6_prow<BM>(wm + li) * X6_ROWB + 16 * lk;
@@ -409,35 +418,34 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     for (int h = 0; h < 2; ++h)
         ft[h] = lds_b + (BN / 32 * 512) * (tg >> 1) + 512 * (wn / 32) + 64 * (4 * h + tq) +
                 16 * ((2 * (tg & 1) + (tp >> 1)) ^ (2 * (tg >> 1) + h)) + 8 * (tp & 1);
-    auto read_b = [&](int b, int p, int s) -> bf16x8 {
+    auto read_b = [&](int b, int p, int s, int so) -> bf16x8 {
         if constexpr (B_PL == 2) {
-            const int o = 512 * b + p * BPL + (BN / 32 * 512) * 2 * s;
+            const int o = so + 512 * b + p * BPL + (BN / 32 * 512) * 2 * s;
             const s16x4 lo = lds_read_tr16(ft[0] + o), hi = lds_read_tr16(ft[1] + o);
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             return __builtin_bit_cast(bf16x8, v);
         } else {
-            return *reinterpret_cast<const bf16x8 *>(fb + b * 8 * X6_ROWB + p * BPL + s * 32);
+            return *reinterpret_cast<const bf16x8 *>(fb + so + b * 8 * X6_ROWB + p * BPL + s * 32);
         }
     };
 
-    auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], uint4 (&xp)[NVP], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA],
-                    float4 (&yb)[NVB], uint4 (&yp)[NVP], unsigned &yma, unsigned &ymb) {
-        if (k0 + 2 * BK < k_end) {
-            stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k0 + 2 * BK, M, k_end, ya, yma);
-            if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k0 + 2 * BK, N, k_end, yp, ymb);
-            else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k0 + 2 * BK, N, k_end, yp, ymb);
-            else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k0 + 2 * BK, N, k_end, yb, ymb);
+    // one k-tile: x = the set holding tile k0 + BK (stored to LDS after the MFMAs), y = the set tile k0 + PD BK is loaded into
+    auto body = [&](int k0, Regs &x, Regs &y, int st) {
+        const int so = LDB ? st * STAGE : 0;                     // stage the MFMAs of this k-tile read
+        if (k0 + PD * BK < k_end) load_tile(y, k0 + PD * BK);
+        if constexpr (LDB) {
+            if (k0 + BK < k_end) store_tile(x, st ^ 1);
         }
         bf16x8 av[2][TM][3], bv[2][TN][3];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) av[0][a][p] = *reinterpret_cast<const bf16x8 *>(fa + a * 8 * X6_ROWB + p * APL);
+            for (int p = 0; p < 3; ++p) av[0][a][p] = *reinterpret_cast<const bf16x8 *>(fa + so + a * 8 * X6_ROWB + p * APL);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bv[0][b][p] = read_b(b, p, 0);
+            for (int p = 0; p < 3; ++p) bv[0][b][p] = read_b(b, p, 0, so);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             if (s + 1 < BK / 16) {
@@ -445,12 +453,12 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        av[(s + 1) & 1][a][p] = *reinterpret_cast<const bf16x8 *>(fa + a * 8 * X6_ROWB + p * APL + (s + 1) * 32);
+                        av[(s + 1) & 1][a][p] = *reinterpret_cast<const bf16x8 *>(fa + so + a * 8 * X6_ROWB + p * APL + (s + 1) * 32);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        bv[(s + 1) & 1][b][p] = read_b(b, p, s + 1);
+                        bv[(s + 1) & 1][b][p] = read_b(b, p, s + 1, so);
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
@@ -467,18 +475,16 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
                     acc[a][b] = c;
                 }
         }
-        __syncthreads();                         // every wave is done reading before the tile is refilled
-        if (k0 + BK < k_end) {
-            stage_store_x6<A_RC, BM, NT, FULL>(lds, xa, xma);
-            if constexpr (B_PL == 2) stage_store_plt<BN, NT>(lds_b, xp, xmb);
-            else if constexpr (B_PL == 1) stage_store_pl<BN, NT>(lds_b, xp, xmb);
-            else stage_store_x6<B_RC, BN, NT, FULL>(lds_b, xb, xmb);
+        if constexpr (!LDB) {
+            __syncthreads();                     // every wave is done reading before the tile is refilled
+            if (k0 + BK < k_end) store_tile(x, 0);
         }
         __syncthreads();
     };
-    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
-        body(k0, ra1, rb1, pb1, ma1, mb1, ra0, rb0, pb0, ma0, mb0);
-        if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, pb0, ma0, mb0, ra1, rb1, pb1, ma1, mb1);
+    for (int k0 = k_begin; k0 < k_end; k0 += PD * BK) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d == 0 || k0 + d * BK < k_end) body(k0 + d * BK, R[(d + 1) % PD], R[d], d & 1);
     }
 }
 
@@ -564,7 +570,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, i
     }
 }
 
-template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, int B_PL = 0>
+template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, int B_PL = 0, bool LDB = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) : 1) k_gemm(GemmArgs g) {
     static_assert(B_PL == 0 || (X6 && (B_PL == 1) == B_RC), "weight planes feed the split-bf16 mainloop: [n][k] planes as the reduction-"
                   "contiguous operand (1), the same planes read along their rows through the transposing LDS read (2)");
@@ -594,7 +600,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
     const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (((B_RC ? k_end : N) & 3) == 0) && (B_RC ? k_end : N) >= 4;
 
     constexpr int AF = tile_floats<A_RC, BM>(), BF = tile_floats<B_RC, BN>();
-    constexpr int LDS_BYTES = X6 ? 3 * (x6_plane_bytes<BM>() + (B_PL == 2 ? plt_plane_bytes<BN>() : x6_plane_bytes<BN>()))
+    static_assert(!LDB || B_PL, "two LDS stages: weight-plane mainloops only");
+    constexpr int LDS_BYTES = X6 ? (LDB ? 2 : 1) * 3 * (x6_plane_bytes<BM>() + (B_PL == 2 ? plt_plane_bytes<BN>() : x6_plane_bytes<BN>()))
                                  : (DBUF ? 2 : 1) * (AF + BF) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     float *lds = reinterpret_cast<float *>(lds_raw);
@@ -616,9 +623,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) 
         const bool full = a_vec && b_vec && m0 + BM <= M && n0 + BN <= N && ((k_end - k_begin) % BK) == 0;
         if (B_PL) {
             const bool fullp = a_vec && m0 + BM <= M && n0 + BN <= N && ((k_end - k_begin) % BK) == 0;
-            if (fullp) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true, B_PL>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
-            else if (a_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, false, B_PL>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
-            else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false, false, B_PL>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            if (fullp) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true, B_PL, LDB>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            else if (a_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, false, B_PL, LDB>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
+            else gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, false, false, B_PL, LDB>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc, g.Bpl[z], g.pl_stride);
         } else
         if (full) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
         else if (a_vec && b_vec) gemm_mainloop_x6<A_RC, B_RC, TM, TN, WGM, WGN, true>(A, B, lda, ldb, m0, n0, M, N, k_begin, k_end, lds_raw, wm, wn, li, lk, acc);
@@ -781,6 +788,7 @@ static int g_gemm_t96 = 0;     // 96x128 tile where it fills the 512 workgroup s
                                // (the side stream's weight-gradient GEMMs already fill the idle slots); kept for A/B
 extern "C" void ppok_debug_set_t96(int v) { g_gemm_t96 = v; }
 
+static const int g_gemm_ldb = getenv("LG_GEMM_LDB") ? atoi(getenv("LG_GEMM_LDB")) : 1;
 template <int EPI, bool B_RC = true, int PL = 1>
 static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
     int maxM = 0, maxN = 0;
@@ -800,7 +808,8 @@ static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
         }
     } else {
         dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), 1, nz);
-        hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 1, 1, false, true, 2, 2, PL>), grid, dim3(256), 0, s, g);
+        if (g_gemm_ldb) hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 1, 1, false, true, 2, 2, PL, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 1, 1, false, true, 2, 2, PL>), grid, dim3(256), 0, s, g);
     }
 }
 static bool planes_ok(const GemmArgs &g, int nz) {
@@ -1028,9 +1037,9 @@ __global__ void k_gather(PpoDev P, int mb) {
 
 // same gather, 32 lanes per row moving 16 bytes each (obs, actions, mu as float4s; the four scalars as one float4):
 // used when O, OC and A are multiples of 4 (every pointer is then 16-byte aligned row by row)
-__global__ void __launch_bounds__(256) k_gather4(PpoDev P, int mb) {
+__device__ __forceinline__ void gather4_block(const PpoDev &P, int mb, int vblock) {
     const int R = P.mb_rows, A4 = P.A / 4, O4 = P.O / 4;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = vblock * 256 + threadIdx.x;
     const int r = gid >> 5, j = gid & 31;
     if (r >= R) return;
     const int src = P.perm[(size_t)mb * R + r];
@@ -1044,6 +1053,7 @@ __global__ void __launch_bounds__(256) k_gather4(PpoDev P, int mb) {
         else reinterpret_cast<float4 *>(P.mb_scalars)[r] = make_float4(P.st_values[src], P.st_returns[src], P.st_adv[src], P.st_log_prob[src]);
     }
 }
+__global__ void __launch_bounds__(256) k_gather4(PpoDev P, int mb) { gather4_block(P, mb, blockIdx.x); }
 
 // PPO.update loss for one minibatch: surrogate, clipped value loss, entropy bonus, KL(old || new);
 // emits d loss / d mu (R x A), d loss / d value (R), and block-reduced d loss / d std, bias grads
@@ -1152,6 +1162,8 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
 // the outer-product weight gradients.  H3 = last hidden width (<= 128).
 #define HEAD_ROWS 64
 #define HEAD_GRID 192
+#define HEAD_NET_GRID 384                                  // workgroups per network of k_head_net (= scratch rows per network)
+#define HEAD_PART_STRIDE(H3) ((LG_PPO_MAX_A + 1) * (H3) + 2 * LG_PPO_MAX_A + 4)
 template <int H3>
 __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__restrict__ xa_g, const float *__restrict__ xc_g,
                                                     float *__restrict__ dza_g, float *__restrict__ dzc_g, int64_t w_a, int64_t b_a,
@@ -1546,22 +1558,12 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
             }
         }
     }
-    __syncthreads();
-    if (tid < 2 * MA + 4) {
-        const int k = tid;
-        const float v = red[k];
-        if (actor) {
-            if (k < MA) { if (k < A) atomicAdd(&P.grads[P.off_std + k], v); }
-            else if (k < 2 * MA) { if (k - MA < A) atomicAdd(&P.grads[b_a + (k - MA)], v); }
-            else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);
-            else if (k == 2 * MA + 3) atomicAdd(&P.loss_acc[1], v);
-        } else {
-            if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
-            else if (k == 2 * MA + 2) atomicAdd(&P.loss_acc[0], v);
-        }
-    }
+    // Sums over the rows of this workgroup leave through a scratch row, not through atomics: 768 workgroups adding into the
+    // same few dozen addresses serialise in L2 (24 us of this kernel's 46 were that queue).  k_head_finish folds the rows.
+    float *__restrict__ prow = P.head_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * HEAD_PART_STRIDE(H3);
     float *acc = x;                                         // reuse the tile buffer: [MA + 1][NH][H3]
     __syncthreads();
+    if (tid < 2 * MA + 4) prow[(MA + 1) * H3 + tid] = red[tid];
     if (half < NH) {
 #pragma unroll
         for (int a = 0; a < MA; ++a) acc[(a * NH + half) * H3 + c] = dw[a];
@@ -1572,8 +1574,49 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
         const int q = i / H3, cc = i % H3;
         float v = 0.f;
         for (int h = 0; h < NH; ++h) v += acc[(q * NH + h) * H3 + cc];
-        if (q < MA) { if (q < nout) atomicAdd(&P.grads[(actor ? w_a : w_c) + (int64_t)q * H3 + cc], v); }
+        prow[i] = v;
+    }
+}
+
+// Folds the scratch rows of k_head_net into the gradient buffer: thread = one sum, blockIdx.y = a chunk of the rows,
+// blockIdx.z = the network; HEAD_FIN_CHUNKS-way atomics instead of 768-way.
+#define HEAD_FIN_CHUNKS 16
+template <int H3>
+__global__ void __launch_bounds__(256) k_head_finish(PpoDev P, int nrows, int64_t w_a, int64_t b_a, int64_t w_c, int64_t b_c, int64_t b_prev_a,
+                                                     int64_t b_prev_c) {
+    constexpr int MA = LG_PPO_MAX_A, NW = (MA + 1) * H3, NTOT = NW + 2 * MA + 4;
+    const int i = blockIdx.x * 256 + threadIdx.x, A = P.A;
+    if (i >= NTOT) return;
+    const bool actor = blockIdx.z == 0;
+    const int nout = actor ? A : 1;
+    // drop the sums nobody consumes before reading anything
+    if (i < NW) { if (i / H3 < MA && i / H3 >= nout) return; }
+    else {
+        const int k = i - NW;
+        const bool used = actor ? ((k < MA && k < A) || (k >= MA && k < 2 * MA && k - MA < A) || k == 2 * MA + 1 || k == 2 * MA + 3)
+                                : (k == 2 * MA || k == 2 * MA + 2);
+        if (!used) return;
+    }
+    const int r0 = (int)((long)nrows * blockIdx.y / HEAD_FIN_CHUNKS), r1 = (int)((long)nrows * (blockIdx.y + 1) / HEAD_FIN_CHUNKS);
+    const float *__restrict__ src = P.head_part + ((size_t)blockIdx.z * nrows + r0) * HEAD_PART_STRIDE(H3) + i;
+    float v = 0.f;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r, src += HEAD_PART_STRIDE(H3)) v += *src;
+    if (i < NW) {
+        const int q = i / H3, cc = i % H3;
+        if (q < MA) atomicAdd(&P.grads[(actor ? w_a : w_c) + (int64_t)q * H3 + cc], v);
         else atomicAdd(&P.grads[(actor ? b_prev_a : b_prev_c) + cc], v);
+    } else {
+        const int k = i - NW;
+        if (actor) {
+            if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
+            else if (k < 2 * MA) atomicAdd(&P.grads[b_a + (k - MA)], v);
+            else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);
+            else atomicAdd(&P.loss_acc[1], v);
+        } else {
+            if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
+            else atomicAdd(&P.loss_acc[0], v);
+        }
     }
 }
 
@@ -1583,7 +1626,10 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
 // count.  k_opt_adam: clip_grad_norm_(max_norm) + torch.optim.Adam step (betas 0.9/0.999, eps 1e-8), then
 // zeroes what it consumed -- the gradient buffer (+ KL tail) for the next minibatch and the OTHER norm slot
 // (par alternates per step, so no block can still be reading the slot that is cleared).
-__global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par) {
+// Workgroups past `prep_blocks` gather the NEXT minibatch into the other buffer set (G = P with that set's pointers): the
+// gather depends on the rollout storage and the permutation only, and this launch leaves most of the chip idle.
+__global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par, int prep_blocks, PpoDev G, int gather_mb) {
+    if ((int)blockIdx.x >= prep_blocks) { gather4_block(G, gather_mb, (int)blockIdx.x - prep_blocks); return; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const float kl = P.grads[P.num_params] / ((float)P.mb_rows * (float)P.world);
         float lr = P.stats[0];
@@ -1601,7 +1647,7 @@ __global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par) {
     }
     float s = 0.f;
     const float inv_world = 1.0f / (float)P.world;
-    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < P.num_params; k += (int64_t)prep_blocks * blockDim.x) {
         float g = P.grads[k] * inv_world;
         s += g * g;
     }
@@ -1680,6 +1726,7 @@ void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
     else
         hipLaunchKernelGGL(k_gather, dim3(P->mb_rows), dim3(64), 0, s, *P, mb);
 }
+size_t ppok_head_part_floats() { return (size_t)2 * HEAD_NET_GRID * HEAD_PART_STRIDE(128); }
 // returns 0 when the fused head kernel supports this width, -1 otherwise (caller falls back to GEMMs + k_loss)
 int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, float *dza, float *dzc, int64_t w_a, int64_t b_a,
                     int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c, hipStream_t s) {
@@ -1688,9 +1735,11 @@ int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, f
     dim3 grid(ntiles < head_grid ? ntiles : head_grid), block(256);
     static const int per_net = getenv("LG_HEAD_PER_NET") ? atoi(getenv("LG_HEAD_PER_NET")) : 1;
     if (H3 == 128 && per_net) {
-        static const int net_grid = getenv("LG_HEAD_GRID") ? atoi(getenv("LG_HEAD_GRID")) : 384;
-        hipLaunchKernelGGL((k_head_net<128>), dim3(ntiles < net_grid ? ntiles : net_grid, 2), block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c,
-                           b_c, b_prev_a, b_prev_c);
+        const int nrows = ntiles < HEAD_NET_GRID ? ntiles : HEAD_NET_GRID;
+        hipLaunchKernelGGL((k_head_net<128>), dim3(nrows, 2), block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+        constexpr int NTOT = HEAD_PART_STRIDE(128);
+        hipLaunchKernelGGL((k_head_finish<128>), dim3((NTOT + 255) / 256, HEAD_FIN_CHUNKS, 2), block, 0, s, *P, nrows, w_a, b_a, w_c, b_c,
+                           b_prev_a, b_prev_c);
     } else if (H3 == 128) hipLaunchKernelGGL((k_head_fused<128>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else if (H3 == 64) hipLaunchKernelGGL((k_head_fused<64>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
     else if (H3 == 32) hipLaunchKernelGGL((k_head_fused<32>), grid, block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
@@ -1701,9 +1750,14 @@ void ppok_loss(const PpoDev *P, const float *mu, const float *v, float *dmu, flo
     hipLaunchKernelGGL(k_loss, dim3((P->mb_rows + 255) / 256), dim3(256), 0, s, *P, mu, v, dmu, dval);
 }
 void ppok_sync_planes(const PpoDev *P, hipStream_t s) { hipLaunchKernelGGL(k_sync_planes, dim3(256), dim3(256), 0, s, *P); }
-void ppok_step(const PpoDev *P, int par, hipStream_t s) {
-    hipLaunchKernelGGL(k_opt_prepare, dim3(128), dim3(256), 0, s, *P, par);
+// G / gather_mb: buffer set and index of a minibatch to gather beside the norm reduction (gather_mb < 0: none); returns
+// whether the gather was taken (the 16-byte row layout of k_gather4)
+int ppok_step(const PpoDev *P, int par, const PpoDev *G, int gather_mb, hipStream_t s) {
+    const bool g4 = gather_mb >= 0 && (P->O & 3) == 0 && (P->A & 3) == 0 && (P->OC & 3) == 0;
+    const int gblocks = g4 ? (P->mb_rows * 32 + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_opt_prepare, dim3(128 + gblocks), dim3(256), 0, s, *P, par, 128, g4 ? *G : *P, gather_mb);
     hipLaunchKernelGGL(k_opt_adam, dim3(256), dim3(256), 0, s, *P, par);
+    return g4 ? 1 : 0;
 }
 }
 

@@ -17,3 +17,19 @@ def oracle_built():
     from oracle import oracle_lib
     oracle_lib.build()
     return oracle_lib
+
+
+@pytest.fixture(autouse=True)
+def _registry_cfgs_restored():
+    """The registered cfg objects are shared and mutated in place (as in the reference: play.py switches randomisation and
+    noise off on them).  Every test gets them back as they were registered, whatever ran before it in the process."""
+    import copy
+    try:
+        from legged_gym_dev_amd.envs import task_registry
+    except Exception:                       # host-only environments without the package's optional imports
+        yield
+        return
+    saved = (copy.deepcopy(task_registry.env_cfgs), copy.deepcopy(task_registry.train_cfgs))
+    yield
+    task_registry.env_cfgs.clear(); task_registry.env_cfgs.update(saved[0])
+    task_registry.train_cfgs.clear(); task_registry.train_cfgs.update(saved[1])

@@ -17,13 +17,22 @@ def timeline(lo, hi):
     return "\n".join(out)
 
 
-gi = [i for i, n in enumerate(names) if n.startswith("k_gather")]
+def pick(starts, must):
+    """the last window [starts[k], starts[k+1]) that contains every kernel of `must` (bench.py also times bare sequences)"""
+    for k in range(len(starts) - 2, -1, -1):
+        w = names[starts[k]:starts[k + 1]]
+        if all(any(m in n for n in w) for m in must):
+            return starts[k], starts[k + 1]
+    raise SystemExit(f"no window with {must}")
+
+
+gi = [i for i, n in enumerate(names) if n.startswith("k_opt_adam")]     # a minibatch period = optimiser step .. next optimiser step
 si = [i for i, n in enumerate(names) if "k_substeps" in n]
-k = -6 if len(gi) > 8 else -2
-print("== one PPO minibatch (gather .. next gather) ==")
-print(timeline(gi[k], gi[k + 1]))
-print(f"   minibatch period: {(int(trace[gi[k + 1]]['Start_Timestamp']) - int(trace[gi[k]]['Start_Timestamp'])) / 1e3:.1f} us")
+lo, hi = pick(gi, ["k_opt_prepare", "k_gemm_dw"])
+print("== one PPO minibatch of the update (optimiser step .. next optimiser step) ==")
+print(timeline(lo, hi))
+print(f"   minibatch period: {(int(trace[hi]['Start_Timestamp']) - int(trace[lo]['Start_Timestamp'])) / 1e3:.1f} us")
 print("\n== one policy step of the rollout (k_substeps .. next k_substeps) ==")
-k = -6 if len(si) > 8 else -2
-print(timeline(si[k], si[k + 1]))
-print(f"   step period: {(int(trace[si[k + 1]]['Start_Timestamp']) - int(trace[si[k]]['Start_Timestamp'])) / 1e3:.1f} us")
+lo, hi = pick(si, ["k_post_step", "k_act_sample"])
+print(timeline(lo, hi))
+print(f"   step period: {(int(trace[hi]['Start_Timestamp']) - int(trace[lo]['Start_Timestamp'])) / 1e3:.1f} us")
