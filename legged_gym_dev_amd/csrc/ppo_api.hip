@@ -14,7 +14,10 @@ extern "C" {
 void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s);
 void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s);
 void ppok_sync_planes(const PpoDev *P, hipStream_t s);
-int ppok_mlp_fwd(const MlpArgs *g, int mask, hipStream_t s);
+int ppok_mlp_fwd(const MlpArgs *g, const PpoDev *P, int mask, hipStream_t s);
+int ppok_mlp_supported(const MlpArgs *g);
+int64_t ppok_mlp_frag_elems(int K, int N);
+void ppok_mlp_frag_build(const MlpArgs *g, hipStream_t s);
 void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s);
 void ppok_debug_set_xcd_remap(int v);
 void ppok_debug_set_dw_t(int v);
@@ -63,7 +66,9 @@ struct lg_ppo {
     int overlap;
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;
-    int fused_act;                           // rollout forward through k_mlp_fwd when the network shape allows (else per-layer GEMMs)                         // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
+    int fused_act;                           // rollout forward through k_mlp_fwd when the network shape allows (else per-layer GEMMs)
+    MlpArgs mlp;                             // its arguments (fragment-order weight image allocated at create)
+                         // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
     int step, inject;
     int64_t act_count, update_count;
     int Mmax;
@@ -237,11 +242,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->cfg = *cfg;
     p->stream = nullptr;
     p->act_code = cfg->activation + 1;
-    // the one-launch rollout forward (ppo_mlp_fused.hip) is one wave per SIMD by its LDS footprint: measured 29 vs 35 us per
-    // act() for [128,64,32] but 68 vs 61 us for [512,256,128], where the per-layer GEMMs' four waves per SIMD win
-    p->fused_act = 1;
-    for (int l = 0; l < cfg->num_hidden; ++l)
-        if (cfg->actor_hidden[l] > 128 || cfg->critic_hidden[l] > 128) p->fused_act = 0;
+    p->fused_act = getenv("LG_FUSED_ACT") ? atoi(getenv("LG_FUSED_ACT")) : 1;   // one-launch rollout forward (ppo_mlp_fused.hip) when the shape allows
     p->overlap = getenv("LG_PPO_OVERLAP") ? atoi(getenv("LG_PPO_OVERLAP")) : 1;
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
@@ -332,6 +333,23 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         n.act[0] = nullptr; n.dz[0] = nullptr;
         for (int l = 1; l <= n.nl; ++l) { PA(n.act[l], (size_t)p->Mmax * n.dims[l]); PA(n.dz[l], (size_t)p->Mmax * n.dims[l]); }
     }
+    if (p->fused_act) {                                         // arguments + weight image of the one-launch rollout forward
+        MlpArgs &g = p->mlp;
+        memset(&g, 0, sizeof(g));
+        g.params = d.params; g.M = N; g.nl = p->net[0].nl; g.act = p->act_code;
+        int64_t tot = 0;
+        if (p->net[0].nl != p->net[1].nl) p->fused_act = 0;
+        for (int z = 0; z < 2 && p->fused_act; ++z) {
+            Net &n = p->net[z];
+            for (int l = 0; l <= n.nl; ++l) g.dims[z][l] = n.dims[l];
+            for (int l = 0; l < n.nl; ++l) {
+                g.w_off[z][l] = n.w_off[l]; g.b_off[z][l] = n.b_off[l]; g.frag_off[z][l] = tot;
+                tot += ppok_mlp_frag_elems(n.dims[l], n.dims[l + 1]);
+            }
+        }
+        if (p->fused_act && ppok_mlp_supported(&g) != 0) p->fused_act = 0;
+        if (p->fused_act) { uint16_t *wf = nullptr; PA(wf, (size_t)tot); g.wfrag = wf; }
+    }
     {   // std = init_noise_std, lr = learning_rate
         std::vector<float> h(A, cfg->init_noise_std);
         (void)hipMemcpy(d.params + d.off_std, h.data(), sizeof(float) * A, hipMemcpyHostToDevice);
@@ -358,7 +376,8 @@ int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out) { *out = p->pub; return 0
 int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0; }
 int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
 int lg_ppo_debug_set_overlap(lg_ppo *p, int v) { p->overlap = v; return 0; }
-int lg_ppo_debug_set_fused_act(lg_ppo *p, int v) { p->fused_act = v; return 0; }
+int lg_ppo_debug_set_fused_act(lg_ppo *p, int v) { p->fused_act = v && p->mlp.wfrag; return 0; }
+int lg_ppo_debug_set_act_count(lg_ppo *p, long long v) { p->act_count = v; return 0; }   // replay the same Philox draws (tests)
 
 // entries: std, then per net per layer (W, b).  offsets[i]; shapes[2i] = rows, shapes[2i+1] = cols (0 for vectors)
 int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_entries) {
@@ -381,27 +400,21 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
     const float *cobs = critic_obs ? critic_obs : obs;
     int fused = -1;
     if (p->fused_act) {
-        // the weight planes follow the parameters inside an update; anything else (load, broadcast) may have
-        // written the fp32 buffer in between, so the first act of a rollout rebuilds them
-        if (p->step == 0) ppok_sync_planes(&p->dev, p->stream);
-        MlpArgs g;
-        memset(&g, 0, sizeof(g));
+        // the image is built from the fp32 parameters by the first act of a rollout (the optimiser, a checkpoint load or the
+        // initial broadcast may have written them since the last one)
+        MlpArgs &g = p->mlp;
         g.in[0] = obs; g.in[1] = cobs;
-        g.params = p->dev.params; g.wpl = p->dev.wpl; g.pl_stride = p->dev.pl_stride;
-        g.M = p->cfg.num_envs; g.nl = p->net[0].nl; g.act = p->act_code;
-        bool same = p->net[0].nl == p->net[1].nl;
-        for (int z = 0; z < 2 && same; ++z) {
-            Net &n = p->net[z];
-            g.out[z] = n.act[n.nl];
-            for (int l = 0; l <= n.nl; ++l) g.dims[z][l] = n.dims[l];
-            for (int l = 0; l < n.nl; ++l) { g.pl_off[z][l] = n.pl_off[l]; g.b_off[z][l] = n.b_off[l]; }
-        }
-        if (same) fused = ppok_mlp_fwd(&g, 3, p->stream);
+        g.out[0] = p->net[0].act[p->net[0].nl]; g.out[1] = p->net[1].act[p->net[1].nl];
+        if (p->step == 0) ppok_mlp_frag_build(&g, p->stream);
+        static const int fuse_sample = getenv("LG_FUSED_SAMPLE") ? atoi(getenv("LG_FUSED_SAMPLE")) : 1;
+        g.sample = fuse_sample; g.t = p->step; g.inject = p->inject; g.act_count = p->act_count;
+        fused = ppok_mlp_fwd(&g, &p->dev, 3, p->stream);
+        if (fused == 0 && g.sample) { p->act_count++; return launch_ok(); }       // sampled and stored by the same launch
     }
     if (fused != 0) {
         // per-layer GEMMs on the optimiser's weight planes (no re-split of W per tile); same freshness rule as above
         static const int act_planes = getenv("LG_ACT_PLANES") ? atoi(getenv("LG_ACT_PLANES")) : 1;
-        if (act_planes && !p->fused_act && p->step == 0) ppok_sync_planes(&p->dev, p->stream);
+        if (act_planes && p->step == 0) ppok_sync_planes(&p->dev, p->stream);
         forward(p, p->cfg.num_envs, obs, cobs, 3, 0, act_planes != 0);
     }
     ppok_act_sample(&p->dev, obs, cobs, p->net[0].act[p->net[0].nl], p->net[1].act[p->net[1].nl], p->step, p->act_count,

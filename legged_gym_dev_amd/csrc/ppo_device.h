@@ -46,3 +46,12 @@ struct PpoDev {                    // passed by value to kernels
     int64_t seg_off[LG_PPO_MAX_SEG], seg_pl[LG_PPO_MAX_SEG];
     int seg_rows[LG_PPO_MAX_SEG], seg_cols[LG_PPO_MAX_SEG];
 };
+
+// standard normal of (seed, env, act() call, action index): Box-Muller on one Philox4x32-10 block (k_act_sample, k_mlp_fwd)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t env, uint64_t step, uint32_t a) {
+    uint32_t c[4] = {env, (uint32_t)step, a, 0x5eedu};
+    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
+    float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}

@@ -870,14 +870,6 @@ extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t 
 
 // ------------------------------------------------------------------------------------------------
 // PPO.act epilogue: a ~ N(mu, sigma), log-prob, transition store (rsl_rl PPO.act / storage.add)
-__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t env, uint64_t step, uint32_t a) {
-    uint32_t c[4] = {env, (uint32_t)step, a, 0x5eedu};
-    philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), c);
-    float u1 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
-    float u2 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-}
-
 __global__ void k_act_sample(PpoDev P, const float *__restrict__ obs, const float *__restrict__ critic_obs,
                              const float *__restrict__ mu, const float *__restrict__ val, int t, int64_t act_count, int inject) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -53,51 +53,57 @@ __device__ __forceinline__ float mlp_act(int code, float v) {
 
 #define MLP_ROWS 32
 #define MLP_KMAX 512
-// B fragments of one k-step: planes h, m, l of W[n][k0 + 8 h .. + 8)
+// Weight image of this kernel ("fragment order", built by k_mlp_frag_build from the fp32 parameters once per rollout): for
+// layer (z, l), column tile t (32 outputs) and k-step ks (16 inputs) the three planes h, m, l are 1 KB blocks
+//      frag_off[z][l] + ((t * K/16 + ks) * 3 + plane) * 512 + lane * 8 + j   =   plane of W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + j]
+// i.e. exactly the B operand of v_mfma_f32_32x32x16_bf16 for that tile and k-step, lane by lane.  A wave's fragment load is
+// one fully coalesced 1 KB read straight into the MFMA operand registers: 8 cache lines per instruction.  Reading the same
+// fragments out of the row-major planes (W[n][k], one 16-byte piece of 32 different rows per instruction) costs the L1 32 tag
+// lookups per instruction and made the launch address-bound: 68 us per act() at [512,256,128] against 61 us for the four
+// per-layer GEMMs.  Output rows past N (the head) are zero in the image.
 struct BFrag { bf16x8 p[3]; };
-__device__ __forceinline__ BFrag mlp_load_b(const uint16_t *__restrict__ w, int64_t pl_stride, int K, int n, int k) {
+__device__ __forceinline__ BFrag mlp_load_frag(const uint16_t *__restrict__ wf, int nks, int tile, int ks, int lane) {
     BFrag f;
-    const uint16_t *q = w + (size_t)n * K + k;
+    const uint16_t *q = wf + ((size_t)(tile * nks + ks) * 3) * 512 + lane * 8;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) f.p[pl] = *reinterpret_cast<const bf16x8 *>(q + pl * pl_stride);
+    for (int pl = 0; pl < 3; ++pl) f.p[pl] = *reinterpret_cast<const bf16x8 *>(q + pl * 512);
     return f;
 }
 
-// One layer for one wave: CT column tiles (n = 32 * (wave + 4 (t0 + i))) advanced together along k, so the A fragment is
-// read and split once per k-step.  k is walked in blocks of S k-steps with the k index PERMUTED inside a block: lane half
-// h owns the contiguous run k = 16 S kb + 8 S h .. + 8 S, its chunk s feeding MFMA k-step s (A uses the same map, the
-// product does not care).  A lane's S loads of a block are then S consecutive 16-byte pieces of one weight row -- with
-// S = 4 a whole 64-byte line, fetched once -- where the natural map touches every line in four widely spaced loads and
-// thrashes the L1.  The next block's fragments are in flight while the current one is multiplied.
+// One layer for one wave: CT column tiles (tile = wave + 4 (t0 + i)) advanced together along k, so the A fragment is read
+// from LDS and split once per k-step.  k is walked in blocks of S k-steps (S CT = 4: twelve 1 KB loads per block and wave, two
+// blocks in flight = 24 KB per wave, enough to cover the L2 round trip at the CU's fill rate).
 template <int CT, int S, int ACT>
 __device__ __forceinline__ void mlp_layer(const MlpArgs &g, int z, int l, const float *__restrict__ cur, float *__restrict__ nxt, int row0,
                                           int wave, int t0, int li, int lk) {
-    const int K = g.dims[z][l], N = g.dims[z][l + 1], ld = K + 4, ldo = N + 4, nkb = K / (16 * S);
+    const int K = g.dims[z][l], N = g.dims[z][l + 1], ld = K + 4, ldo = N + 4, nks = K / 16, nkb = (nks + S - 1) / S;
+    const int lane = li + 32 * lk;
     const bool head = l == g.nl - 1;
-    const uint16_t *__restrict__ w = g.wpl + g.pl_off[z][l];
-    const float *__restrict__ arow = cur + li * ld + 8 * S * lk;
-    int n[CT], nc[CT];
+    const uint16_t *__restrict__ wf = g.wfrag + g.frag_off[z][l];
+    const float *__restrict__ arow = cur + li * ld + 8 * lk;
+    int tile[CT], n[CT];
     f32x16 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        n[c] = (wave + 4 * (t0 + c)) * 32 + li;
-        nc[c] = min(n[c], N - 1);                     // clamped: columns past N are computed on row N-1, never stored
+        tile[c] = wave + 4 * (t0 + c);
+        n[c] = tile[c] * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     }
     BFrag bf[2][S][CT];
     auto load_block = [&](BFrag (&dst)[S][CT], int kb) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
+        for (int q = 0; q < S; ++q)
 #pragma unroll
-            for (int q = 0; q < S; ++q) dst[q][c] = mlp_load_b(w, g.pl_stride, K, nc[c], 16 * S * kb + 8 * S * lk + 8 * q);
+            for (int c = 0; c < CT; ++c) dst[q][c] = mlp_load_frag(wf, nks, tile[c], min(S * kb + q, nks - 1), lane);
     };
     auto mul_block = [&](const BFrag (&src)[S][CT], int kb) {
 #pragma unroll
         for (int q = 0; q < S; ++q) {
+            if (S * kb + q >= nks) break;                              // tail of a K that is not a whole number of blocks (uniform)
             float x[8];
-            *reinterpret_cast<float4 *>(x) = *reinterpret_cast<const float4 *>(arow + 16 * S * kb + 8 * q);
-            *reinterpret_cast<float4 *>(x + 4) = *reinterpret_cast<const float4 *>(arow + 16 * S * kb + 8 * q + 4);
+            *reinterpret_cast<float4 *>(x) = *reinterpret_cast<const float4 *>(arow + 16 * (S * kb + q));
+            *reinterpret_cast<float4 *>(x + 4) = *reinterpret_cast<const float4 *>(arow + 16 * (S * kb + q) + 4);
             bf16x8 ah, am, al;
             mlp_split8(x, ah, am, al);
 #pragma unroll
@@ -133,7 +139,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs &g, int z, int l, const 
     // acc[c][r]: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        const float bv = g.params[g.b_off[z][l] + nc[c]];
+        const float bv = g.params[g.b_off[z][l] + min(n[c], N - 1)];
         if (!head) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -143,26 +149,50 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs &g, int z, int l, const 
         } else if (n[c] < N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (gr < g.M) g.out[z][(size_t)gr * N + n[c]] = acc[c][r] + bv;
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * lk, gr = row0 + lr;
+                if (g.sample) nxt[lr * ldo + n[c]] = acc[c][r] + bv;     // stays in LDS for the sampling epilogue
+                else if (gr < g.M) g.out[z][(size_t)gr * N + n[c]] = acc[c][r] + bv;
             }
         }
     }
 }
-// S = 4 with at most two column tiles at a time (register budget of the two fragment sets), S = 1 for short or odd K
-template <int S, int ACT>
+// the column tiles of a wave, four / two / one at a time (S CT = 4)
+template <int ACT>
 __device__ __forceinline__ void mlp_layer_tiles(const MlpArgs &g, int z, int l, const float *cur, float *nxt, int row0, int wave, int mine,
                                                 int li, int lk) {
-    constexpr int CMAX = S == 4 ? 2 : 4;
     for (int t0 = 0; t0 < mine;) {
-        const int c = min(CMAX, mine - t0);
-        if (c == 4) { if constexpr (CMAX >= 4) mlp_layer<4, S, ACT>(g, z, l, cur, nxt, row0, wave, t0, li, lk); t0 += 4; }
-        else if (c >= 2) { mlp_layer<2, S, ACT>(g, z, l, cur, nxt, row0, wave, t0, li, lk); t0 += 2; }
-        else { mlp_layer<1, S, ACT>(g, z, l, cur, nxt, row0, wave, t0, li, lk); t0 += 1; }
+        const int c = mine - t0;
+        if (c >= 4) { mlp_layer<4, 1, ACT>(g, z, l, cur, nxt, row0, wave, t0, li, lk); t0 += 4; }
+        else if (c >= 2) { mlp_layer<2, 2, ACT>(g, z, l, cur, nxt, row0, wave, t0, li, lk); t0 += 2; }
+        else { mlp_layer<1, 4, ACT>(g, z, l, cur, nxt, row0, wave, t0, li, lk); t0 += 1; }
     }
 }
 
-__global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g) {
+// fp32 parameters -> fragment-order image (one thread per 8 consecutive k of one output row and plane triple)
+__global__ void __launch_bounds__(256) k_mlp_frag_build(MlpArgs g, uint16_t *__restrict__ wf) {
+    for (int z = 0; z < 2; ++z)
+        for (int l = 0; l < g.nl; ++l) {
+            const int K = g.dims[z][l], N = g.dims[z][l + 1], nks = K / 16, tiles = (N + 31) / 32;
+            const float *__restrict__ W = g.params + g.w_off[z][l];
+            uint16_t *__restrict__ dst = wf + g.frag_off[z][l];
+            const int total = tiles * nks * 64;                       // (tile, ks, lane)
+            for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+                const int lane = i & 63, ks = (i >> 6) % nks, tile = (i >> 6) / nks;
+                const int n = tile * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5);
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = n < N ? W[(size_t)n * K + k + j] : 0.f;
+                bf16x8 h, m, lo;
+                mlp_split8(x, h, m, lo);
+                uint16_t *q = dst + ((size_t)(tile * nks + ks) * 3) * 512 + lane * 8;
+                *reinterpret_cast<bf16x8 *>(q) = h;
+                *reinterpret_cast<bf16x8 *>(q + 512) = m;
+                *reinterpret_cast<bf16x8 *>(q + 1024) = lo;
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
     const int z = blockIdx.y;
     const int row0 = blockIdx.x * MLP_ROWS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
@@ -174,7 +204,14 @@ __global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g) {
         for (int i = tid; i < MLP_ROWS * K; i += 256) {
             const int r = i / K, k = i - r * K;
             const int gr = min(row0 + r, g.M - 1);
-            cur[r * ld + k] = g.in[z][(size_t)gr * K + k];
+            const float v = g.in[z][(size_t)gr * K + k];
+            cur[r * ld + k] = v;
+            // storage.add of the observations (rsl_rl RolloutStorage): the actor workgroup stores its rows, the critic's its own
+            // when the critic has privileged observations
+            if (g.sample && g.t >= 0 && row0 + r < g.M) {
+                if (z == 0) P.st_obs[((size_t)g.t * g.M + gr) * K + k] = v;
+                else if (P.st_critic_obs != P.st_obs) P.st_critic_obs[((size_t)g.t * g.M + gr) * K + k] = v;
+            }
         }
     }
     __syncthreads();
@@ -182,30 +219,68 @@ __global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g) {
         const int ntiles = (g.dims[z][l + 1] + 31) / 32;
         // column tiles of this wave: wave, wave + 4, ... (workgroup-uniform count per wave up to rounding)
         const int mine = ntiles > wave ? (ntiles - wave + 3) / 4 : 0;
-        if (g.act == 1) {
-            if (g.dims[z][l] % 64 == 0) mlp_layer_tiles<4, 1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
-            else mlp_layer_tiles<1, 1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
-        } else {
-            if (g.dims[z][l] % 64 == 0) mlp_layer_tiles<4, -1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
-            else mlp_layer_tiles<1, -1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
-        }
+        if (g.act == 1) mlp_layer_tiles<1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
+        else mlp_layer_tiles<-1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
         __syncthreads();
         float *t = cur; cur = nxt; nxt = t;
+    }
+    if (!g.sample) return;
+    // ---- PPO.act epilogue (the arithmetic of k_act_sample, term by term): cur = head outputs [32][N + 4]
+    const int A = P.A, t = g.t, N = g.M, ldh = g.dims[z][g.nl] + 4;
+    if (z == 0) {
+        const float *std = P.params + P.off_std;
+        if (blockIdx.x == 0 && tid < A && t == 0) P.st_sigma[tid] = std[tid];
+        float *lpt = nxt;                                             // log-prob terms [32][A]
+        for (int e = tid; e < MLP_ROWS * A; e += 256) {
+            const int r = e / A, a = e - r * A, i = row0 + r;
+            if (i >= N) continue;
+            const float m = cur[r * ldh + a], s = std[a];
+            const float zn = g.inject ? P.noise[(size_t)i * A + a] : philox_normal(P.seed, (uint32_t)(P.env_offset + i), (uint64_t)g.act_count, a);
+            const float act = m + s * zn;
+            lpt[r * A + a] = -((act - m) * (act - m)) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+            P.act_actions[(size_t)i * A + a] = act;
+            P.act_mu[(size_t)i * A + a] = m;
+            if (t >= 0) {
+                P.st_actions[((size_t)t * N + i) * A + a] = act;
+                P.st_mu[((size_t)t * N + i) * A + a] = m;
+            }
+        }
+        __syncthreads();
+        if (tid < MLP_ROWS && row0 + tid < N) {
+            const int i = row0 + tid;
+            float lp = 0.f;
+            for (int a = 0; a < A; ++a) lp += lpt[tid * A + a];
+            P.act_log_prob[i] = lp;
+            if (t >= 0) P.st_log_prob[(size_t)t * N + i] = lp;
+        }
+    } else if (tid < MLP_ROWS && row0 + tid < N) {
+        const int i = row0 + tid;
+        const float v = cur[tid * ldh];
+        P.act_values[i] = v;
+        if (t >= 0) P.st_values[(size_t)t * N + i] = v;
     }
 }
 
 // 0 when the fused kernel covers this network shape, -1 otherwise (caller runs the per-layer GEMMs)
-extern "C" int ppok_mlp_fwd(const MlpArgs *g, int mask, hipStream_t s) {
-    for (int z = 0; z < 2; ++z) {
-        if (!(mask & (1 << z))) continue;
+extern "C" int ppok_mlp_supported(const MlpArgs *g) {
+    for (int z = 0; z < 2; ++z)
         for (int l = 0; l < g->nl; ++l) {
             const int K = g->dims[z][l], N = g->dims[z][l + 1];
-            if (K % 16 || K > MLP_KMAX || K < 16 || (g->pl_off[z][l] & 7)) return -1;
+            if (K % 16 || K > MLP_KMAX || K < 16) return -1;
             if (l < g->nl - 1 && (N % 32 || N > MLP_KMAX)) return -1;
         }
-    }
-    if (mask != 3 || (g->pl_stride & 7) || ((uintptr_t)g->wpl & 15)) return -1;
+    return 0;
+}
+// bf16 elements of the fragment-order image of layer (K inputs, N outputs)
+extern "C" int64_t ppok_mlp_frag_elems(int K, int N) { return (int64_t)((N + 31) / 32) * 32 * K * 3; }
+extern "C" void ppok_mlp_frag_build(const MlpArgs *g, hipStream_t s) {
+    hipLaunchKernelGGL(k_mlp_frag_build, dim3(256), dim3(256), 0, s, *g, const_cast<uint16_t *>(g->wfrag));
+}
+// P: the learner's device struct (sampling epilogue when g->sample; otherwise only passed through)
+extern "C" int ppok_mlp_fwd(const MlpArgs *g, const PpoDev *P, int mask, hipStream_t s) {
+    if (mask != 3 || ppok_mlp_supported(g) || ((uintptr_t)g->wfrag & 15)) return -1;
+    if (g->sample && (g->M != P->N || g->dims[0][g->nl] != P->A || g->dims[1][g->nl] != 1 || P->A > LG_PPO_MAX_A)) return -1;
     dim3 grid((g->M + MLP_ROWS - 1) / MLP_ROWS, 2);
-    hipLaunchKernelGGL(k_mlp_fwd, grid, dim3(256), 0, s, *g);
+    hipLaunchKernelGGL(k_mlp_fwd, grid, dim3(256), 0, s, *g, *P);
     return 0;
 }

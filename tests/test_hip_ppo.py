@@ -67,6 +67,36 @@ def test_act_matches_torch(O, hidden):
     hip.close()
 
 
+def test_one_launch_act_equals_per_layer_act():
+    """lg_ppo_act as ONE launch (fragment-order weights, sampling + transition store in the epilogue: ppo_mlp_fused.hip) against
+    the per-layer GEMMs + k_act_sample on the same learner: sampled actions, log-probs, values and the stored transition.
+    Philox noise (not injected): both paths draw the same stream.  Means / values go through differently tiled fp32 sums."""
+    N, O, A, T = 333, 48, 12, 3
+    hip, _, _ = _make(N, O, A, T)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    obs = [torch.randn(N, O, device="cuda", generator=g) for _ in range(T)]
+    got = []
+    for fused in (1, 0):
+        hip.lib.lg_ppo_debug_set_fused_act(hip.ctx, fused)
+        hip.lib.lg_ppo_debug_set_act_count(hip.ctx, 0)
+        rec = []
+        for t in range(T):
+            a = hip.act(obs[t]).clone()
+            rec.append((a, hip.t["act_log_prob"].clone(), hip.t["act_values"].clone(), hip.t["act_mu"].clone()))
+            hip.process_env_step(torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"), {})
+        st = {k: hip.t[k].clone() for k in ("obs", "actions", "mu", "values", "log_prob", "sigma")}
+        got.append((rec, st))
+        hip._call("end_update")                      # rewind the rollout cursor
+    (ra, sa), (rb, sb) = got
+    for t in range(T):
+        for x, y in zip(ra[t], rb[t]):
+            torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-5)
+    for k in sa:
+        torch.testing.assert_close(sa[k], sb[k], rtol=2e-5, atol=2e-5, msg=k)
+    assert torch.equal(sa["obs"], sb["obs"]) and torch.equal(sa["obs"][1], obs[1])
+    hip.close()
+
+
 def test_philox_sampling_is_standard_normal():
     hip, ac, _ = _make(4096, 48, 12, 2, dict(POLICY, actor_hidden_dims=[32, 32, 32], critic_hidden_dims=[32, 32, 32]))
     obs = torch.zeros(4096, 48, device="cuda")
