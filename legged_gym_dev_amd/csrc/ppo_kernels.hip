@@ -378,11 +378,11 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     constexpr int NVA = BM * BK / 4 / NT, NVB = BN * BK / 4 / NT;
     // two register sets: the global loads of k-tile t+2 are issued before the MFMAs of tile t, and tile t+1 (already
     // landed) is split and stored after them -- one full iteration to cover the L2/HBM latency.
-    // LDB: two LDS stages.  With one stage an iteration is MFMAs | barrier | split + store | barrier, every wave in lock
-    // step, so the matrix pipe idles while the VALU splits and vice versa; that is hidden when a SIMD holds waves of
-    // several workgroups (the 128-row update configurations: 4 per SIMD) but not in the 64x64 configuration of the
-    // rollout forward (tools/gemm_small_bench.py: 0.70 us per k-tile with the machine otherwise idle).  With two stages
-    // the split + store of tile t+1 goes to the other stage with no barrier before it and overlaps the MFMAs of tile t.
+    // LDB: two LDS stages -- the split + store of tile t+1 goes to the other stage with no barrier before it and can overlap
+    // the MFMAs of tile t (one barrier per k-tile instead of two).  Built for the 64x64 configuration; measured NEUTRAL there
+    // (12.5 vs 13.1 us per rollout GEMM; tools/kernel_avg.sh), as was a prefetch distance of 4: those launches are bound by
+    // their fixed cost (~7 us for a K = 48 or K = 128 layer) and were replaced by the one-launch forward of ppo_mlp_fused.hip.
+    // Kept selectable (LG_GEMM_LDB) for shapes the fused forward does not cover; off by default.
     constexpr int PD = 2;
     constexpr int NVP = B_PL ? BN * 12 / NT : 1;                 // 16-byte chunks of a plane k-tile per thread (either plane layout)
     struct Regs { float4 a[NVA], b[NVB]; uint4 p[NVP]; unsigned ma = 0, mb = 0; };
@@ -788,7 +788,7 @@ static int g_gemm_t96 = 0;     // 96x128 tile where it fills the 512 workgroup s
                                // (the side stream's weight-gradient GEMMs already fill the idle slots); kept for A/B
 extern "C" void ppok_debug_set_t96(int v) { g_gemm_t96 = v; }
 
-static const int g_gemm_ldb = getenv("LG_GEMM_LDB") ? atoi(getenv("LG_GEMM_LDB")) : 1;
+static const int g_gemm_ldb = getenv("LG_GEMM_LDB") ? atoi(getenv("LG_GEMM_LDB")) : 0;
 template <int EPI, bool B_RC = true, int PL = 1>
 static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
     int maxM = 0, maxN = 0;

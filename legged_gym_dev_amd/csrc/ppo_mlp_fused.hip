@@ -52,6 +52,10 @@ __device__ __forceinline__ float mlp_act(int code, float v) {
 }
 
 #define MLP_ROWS 32
+#ifndef MLP_NW
+#define MLP_NW 4                 // waves per workgroup
+#endif
+#define MLP_NT (64 * MLP_NW)
 #define MLP_KMAX 512
 // Weight image of this kernel ("fragment order", built by k_mlp_frag_build from the fp32 parameters once per rollout): for
 // layer (z, l), column tile t (32 outputs) and k-step ks (16 inputs) the three planes h, m, l are 1 KB blocks
@@ -85,7 +89,7 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs &g, int z, int l, const 
     f32x16 acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        tile[c] = wave + 4 * (t0 + c);
+        tile[c] = wave + MLP_NW * (t0 + c);
         n[c] = tile[c] * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
@@ -106,18 +110,14 @@ __device__ __forceinline__ void mlp_layer(const MlpArgs &g, int z, int l, const 
             *reinterpret_cast<float4 *>(x + 4) = *reinterpret_cast<const float4 *>(arow + 16 * (S * kb + q) + 4);
             bf16x8 ah, am, al;
             mlp_split8(x, ah, am, al);
+            // the six term products, smallest first; column tiles interleaved so that consecutive MFMAs never share an accumulator
+            const bf16x8 *ax[3] = {&ah, &am, &al};
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const BFrag &b = src[q][c];
-                f32x16 a = acc[c];
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.p[1], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.p[2], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.p[0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.p[1], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b.p[0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.p[0], a, 0, 0, 0);
-                acc[c] = a;
-            }
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*ax[PA[t]], src[q][c].p[PB[t]], acc[c], 0, 0, 0);
         }
     };
     // sched_barrier: hipcc otherwise sinks the prefetch loads down to their uses and waits on each (vmcnt(0..5) all over
@@ -192,16 +192,23 @@ __global__ void __launch_bounds__(256) k_mlp_frag_build(MlpArgs g, uint16_t *__r
         }
 }
 
-__global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
+__global__ void __launch_bounds__(MLP_NT, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
     const int z = blockIdx.y;
     const int row0 = blockIdx.x * MLP_ROWS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
     __shared__ __attribute__((aligned(16))) float s_a[MLP_ROWS * (MLP_KMAX + 4)];
     __shared__ __attribute__((aligned(16))) float s_b[MLP_ROWS * (MLP_KMAX + 4)];
     float *cur = s_a, *nxt = s_b;
+#ifdef MLP_PROF                      // section timing (tools/mlp_sections.py): s_memtime deltas of wave 0 into P.noise
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+    int t_k = 0;
+#define MSTAMP() do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tid == 0 && blockIdx.x < 32) P.noise[(blockIdx.y * 32 + blockIdx.x) * 8 + t_k] = (float)(t_ - t_last); t_last = t_; ++t_k; } while (0)
+#else
+#define MSTAMP() do { } while (0)
+#endif
     {   // observations of the 32 rows -> LDS (rows past M read the last row: computed, never stored)
         const int K = g.dims[z][0], ld = K + 4;
-        for (int i = tid; i < MLP_ROWS * K; i += 256) {
+        for (int i = tid; i < MLP_ROWS * K; i += MLP_NT) {
             const int r = i / K, k = i - r * K;
             const int gr = min(row0 + r, g.M - 1);
             const float v = g.in[z][(size_t)gr * K + k];
@@ -215,13 +222,15 @@ __global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
         }
     }
     __syncthreads();
+    MSTAMP();
     for (int l = 0; l < g.nl; ++l) {
         const int ntiles = (g.dims[z][l + 1] + 31) / 32;
         // column tiles of this wave: wave, wave + 4, ... (workgroup-uniform count per wave up to rounding)
-        const int mine = ntiles > wave ? (ntiles - wave + 3) / 4 : 0;
+        const int mine = ntiles > wave ? (ntiles - wave + MLP_NW - 1) / MLP_NW : 0;
         if (g.act == 1) mlp_layer_tiles<1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
         else mlp_layer_tiles<-1>(g, z, l, cur, nxt, row0, wave, mine, li, lk);
         __syncthreads();
+        MSTAMP();
         float *t = cur; cur = nxt; nxt = t;
     }
     if (!g.sample) return;
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
         const float *std = P.params + P.off_std;
         if (blockIdx.x == 0 && tid < A && t == 0) P.st_sigma[tid] = std[tid];
         float *lpt = nxt;                                             // log-prob terms [32][A]
-        for (int e = tid; e < MLP_ROWS * A; e += 256) {
+        for (int e = tid; e < MLP_ROWS * A; e += MLP_NT) {
             const int r = e / A, a = e - r * A, i = row0 + r;
             if (i >= N) continue;
             const float m = cur[r * ldh + a], s = std[a];
@@ -259,6 +268,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
         P.act_values[i] = v;
         if (t >= 0) P.st_values[(size_t)t * N + i] = v;
     }
+    MSTAMP();
 }
 
 // 0 when the fused kernel covers this network shape, -1 otherwise (caller runs the per-layer GEMMs)
@@ -281,6 +291,6 @@ extern "C" int ppok_mlp_fwd(const MlpArgs *g, const PpoDev *P, int mask, hipStre
     if (mask != 3 || ppok_mlp_supported(g) || ((uintptr_t)g->wfrag & 15)) return -1;
     if (g->sample && (g->M != P->N || g->dims[0][g->nl] != P->A || g->dims[1][g->nl] != 1 || P->A > LG_PPO_MAX_A)) return -1;
     dim3 grid((g->M + MLP_ROWS - 1) / MLP_ROWS, 2);
-    hipLaunchKernelGGL(k_mlp_fwd, grid, dim3(256), 0, s, *g, *P);
+    hipLaunchKernelGGL(k_mlp_fwd, grid, dim3(MLP_NT), 0, s, *g, *P);
     return 0;
 }
