@@ -46,12 +46,23 @@ for r in stats[:24]:
 trace = list(csv.DictReader(open(one(f"{tag}_prof/*/*kernel_trace.csv"))))
 trace.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in trace]
-gi = [i for i, n in enumerate(names) if n.startswith("k_gather")]
-mb = names[gi[-2]:gi[-1]]                         # one minibatch: gather .. optimiser step
-si = [i for i, n in enumerate(names) if "k_substeps" in n]
-st = names[si[-2]:si[-1]]                         # one policy step: substeps .. act of the next
+def window(starts, must):
+    """the last window [starts[k], starts[k+1]) holding every kernel of `must` (bench.py also launches bare timing loops)"""
+    for k in range(len(starts) - 2, -1, -1):
+        w = names[starts[k]:starts[k + 1]]
+        if all(any(m in n for n in w) for m in must):
+            return starts[k], starts[k + 1]
+    raise SystemExit(f"no window with {must}")
+
+
+# one minibatch of the update = optimiser step .. next optimiser step (the gather of the next minibatch rides in k_opt_prepare);
+# the GEMM group bench.py times = gather + forward + head + backward of one lg_ppo_minibatch_backward
+gi = window([i for i, n in enumerate(names) if n.startswith("k_opt_adam")], ["k_opt_prepare", "k_gemm_dw"])
+mb = names[gi[0]:gi[1]]
+si = window([i for i, n in enumerate(names) if "k_substeps" in n], ["k_post_step", "k_mlp_fwd"])
+st = names[si[0]:si[1]]                         # one policy step: substeps .. act of the next
 kib = lambda n: (2.0 * sum(fetch[n]) / len(fetch[n]) if n in fetch else 0.0) + (sum(write[n]) / len(write[n]) if n in write else 0.0)
-group = [n for n in mb if "k_gemm" in n or n.startswith(("k_gather", "k_loss")) or "k_head" in n]
+group = [n for n in mb if "k_gemm" in n or n.startswith("k_loss") or "k_head" in n] + ["k_gather4(PpoDev, int)"]
 envk = [n for n in st if "k_substeps" in n or "k_post_step" in n or "k_finalize" in n]
 out = {"policy_hidden": [512, 256, 128],
        "gemm_group_bytes_per_minibatch": round(1024.0 * sum(kib(n) for n in group)),
@@ -70,8 +81,8 @@ def timeline(lo, hi):
         rows.append(f"{s / 1e3:9.1f} {e / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  {r['Kernel_Name'][:70]}  grid {r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}")
     return "\n".join(rows)
 open(os.path.join(pr, f"{tag}_timelines.txt"), "w").write(
-    "== one PPO minibatch (gather .. optimiser step), profiled ==\n" + timeline(gi[-2], gi[-1]) +
-    "\n\n== one policy step of the rollout (k_substeps .. next k_substeps), profiled ==\n" + timeline(si[-2], si[-1]) + "\n")
+    "== one PPO minibatch of the update (optimiser step .. next optimiser step), profiled ==\n" + timeline(gi[0], gi[1]) +
+    "\n\n== one policy step of the rollout (k_substeps .. next k_substeps), profiled ==\n" + timeline(si[0], si[1]) + "\n")
 for f in (f"{tag}_gpu_tests.log", f"{tag}_bench_n1.json"):
     if os.path.exists(os.path.join(go, f)):
         shutil.copy(os.path.join(go, f), os.path.join(pr, f))
