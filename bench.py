@@ -194,7 +194,7 @@ def env_roofline(env, reps=50):
             pmc = json.load(f)
     except (OSError, ValueError, KeyError):
         pass
-    out = {"bound": "valu-issue", "kernel": "k_substeps<4,3,true> (clip + 4 x {actuator net, ABA + contact}): one launch per policy step",
+    out = {"bound": "valu-issue", "kernel": "k_substeps<4,3,true,true> (clip + 4 x {actuator net, pair-lane ABA + contact}): one launch per policy step",
            "us_per_launch": round(ms_loop * 1e3, 2), "us_per_lg_step": round(ms * 1e3, 2),
            "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                    "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP}}
