@@ -143,7 +143,7 @@ __device__ __forceinline__ Ground ground_at(const DevParams *P, float x, float y
 
 
 
-#define LG_CT_NF 17      // floats per contact-slot record
+#define LG_CT_NF 19      // floats per contact-slot record: Pc 3 (sphere centre before detection), n 3, W 6, target, impulses 3, first tangent 3 (pair-lane physics)
 #define LG_LK_NF 24      // floats per link record: R 9, p 3, vel 6, c 6
 __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
     V3 ref = fabsf(n.x) < 0.9f ? V3{1.f, 0.f, 0.f} : V3{0.f, 1.f, 0.f};

@@ -151,8 +151,11 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
     const V3 gb = mulT(Rb, V3{c.gravity[0], c.gravity[1], c.gravity[2]});
     const V3 vel0 = sel3(h, vb, wb), vel0o = sel3(h, wb, vb);
     const V3 zero3 = {0.f, 0.f, 0.f};
+    const int nslots = P->n_leg_slots;
+    const unsigned long long link_pk = P->slot_link_pk;      // sphere slot -> link, 4 bits per slot
 
 #define LKP(j, f) lkp[((j) * LG_LKP_NF + (f)) * 64 + pcol]
+#define CF(si, f) cst[((si) * LG_CT_NF + (f)) * 64 + pcol]
 #define LKH(j, f) lkh[((j) * LG_LKH_NF + (f)) * 128 + lcol]
     V3 S[J], U[J];                                       // my halves
     float iD[J], u[J];
@@ -180,6 +183,14 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
             LKP(j, 9) = pj.x; LKP(j, 10) = pj.y; LKP(j, 11) = pj.z;
             LKH(j, 0) = velj.x; LKH(j, 1) = velj.y; LKH(j, 2) = velj.z;
             LKH(j, 3) = cbj.x; LKH(j, 4) = cbj.y; LKH(j, 5) = cbj.z;
+            // base-frame centres of this link's collision spheres, while R and p are in registers (wave-uniform slot -> link
+            // table): the detection loop below then needs three LDS reads per slot instead of the link tile
+#pragma unroll
+            for (int sl = 0; sl < LG_MAX_LEG_SLOTS; ++sl)
+                if (sl < nslots && (int)((link_pk >> (4 * sl)) & 15ull) == j) {
+                    const V3 cs = pj + mul(Rlj, ld3(lt + LG_LT_SLOTS + 4 * sl));
+                    CF(sl, 0) = cs.x; CF(sl, 1) = cs.y; CF(sl, 2) = cs.z;
+                }
             Rpar = Rlj; ppar = pj; vpar = velj; vparo = veljo;
         }
     }
@@ -268,10 +279,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
     // ---- contact detection + W per slot.  The records are shared by the pair: both lanes compute and store the same
     // values to the same column (each lane reads back what it wrote itself; no cross-lane ordering is relied on).
     const float mu = 0.5f * (friction + c.ground_friction);
-    const int nslots = P->n_leg_slots;
-#define CF(si, f) cst[((si) * LG_CT_NF + (f)) * 64 + pcol]
     unsigned amask = 0u;
-    const unsigned long long link_pk = P->slot_link_pk;
     const int nbase_it = (P->n_base_spheres + L - 1) / L;
     for (int s = 0; s < nslots + nbase_it; ++s) {
         const bool is_base = s >= nslots;
@@ -286,12 +294,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
                 cbk = ld3(lt + LG_LT_BASE + 4 * ub);
                 rad = lt[LG_LT_BASE + 4 * ub + 3];
             } else {
-                const int jl = (int)((link_pk >> (4 * s)) & 15ull);
-                M3 Rk;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) Rk.m[e / 3][e % 3] = LKP(jl, e);
-                const V3 pk = {LKP(jl, 9), LKP(jl, 10), LKP(jl, 11)};
-                cbk = pk + mul(Rk, ld3(lt + LG_LT_SLOTS + 4 * s));
+                cbk = {CF(s, 0), CF(s, 1), CF(s, 2)};              // from the kinematics pass
                 rad = lt[LG_LT_SLOTS + 4 * s + 3];
             }
             V3 cw = xw + mul(Rb, cbk);
@@ -346,6 +349,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
             for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
         }
         if (valid) {
+            CF(si, 16) = t1.x; CF(si, 17) = t1.y; CF(si, 18) = t1.z;   // first tangent: the sweeps and the force output rebuild t2 = n x t1 only
             CF(si, 6) = Wc[0][0] > 1e-9f ? frcp(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
             CF(si, 9) = Wc[1][1] > 1e-9f ? frcp(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
             CF(si, 11) = Wc[2][2] > 1e-9f ? frcp(Wc[2][2]) : 0.f;
@@ -422,8 +426,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
                 const V3 vP = part + px3(part);
                 if (active) {
                     const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
-                    V3 t1, t2;
-                    tangents(nb, t1, t2);
+                    const V3 t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}, t2 = cross(nb, t1);
                     float vc0 = dot(nb, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
                     float ln = fmaxf(0.0f, oln - relax * (vc0 - CF(si, 12)) * CF(si, 6));
                     float dn = ln - oln;
@@ -482,8 +485,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
         V3 f = {0.f, 0.f, 0.f};
         if ((amask >> si) & 1u) {
             const V3 nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
-            V3 t1, t2;
-            tangents(nb, t1, t2);
+            const V3 t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}, t2 = cross(nb, t1);
             f = inv_dt * mul(Rb, CF(si, 13) * nb + CF(si, 14) * t1 + CF(si, 15) * t2);
         }
         if (si >= LG_MAX_LEG_SLOTS) fbase = fbase + f; else fslot[si] = f;
