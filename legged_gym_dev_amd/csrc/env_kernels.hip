@@ -944,10 +944,13 @@ extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipSt
     int blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_set_actions, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, P, a);
 }
-// LG_PHYS_PAIR=0 selects the one-lane-per-leg physics (lg_physics.h) for A/B runs; the default is the pair-lane map.
+// The one-lane-per-leg physics (lg_physics.h) stays selectable for A/B runs and for the equivalence test of the two lane maps:
+// LG_PHYS_PAIR=0 in the environment, or lg_debug_set_phys_pair() at run time.  Default: the pair-lane map.
+static int g_phys_pair = -1;
+extern "C" void lgk_debug_set_phys_pair(int v) { g_phys_pair = v ? 1 : 0; }
 static int phys_pair_enabled() {
-    static const int v = [] { const char *e = getenv("LG_PHYS_PAIR"); return e ? atoi(e) : 1; }();
-    return v;
+    if (g_phys_pair < 0) { const char *e = getenv("LG_PHYS_PAIR"); g_phys_pair = e ? (atoi(e) ? 1 : 0) : 1; }
+    return g_phys_pair;
 }
 template <int L, int J, bool LSTM>
 static void launch_substeps(int blocks, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {

@@ -242,6 +242,58 @@ def test_fused_control_loop_equals_launch_per_substep(name):
         b.close()
 
 
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
+def test_pair_lane_physics_equals_one_lane_per_leg(name):
+    """The two lane maps of the physics -- two lanes per (env, leg) splitting every spatial quantity by rows (lg_physics_pair.h,
+    the default) and one lane per (env, leg) (lg_physics.h) -- are the same algorithm with differently associated fp32 sums.
+    From bit-identical states with feet, shanks and (Cassie) joint stops in play, one lg_simulate under each map: joint state,
+    root state and contact forces agree to 2e-5 relative to the buffer's scale (contacts amplify beyond one substep, which is why
+    the comparison restarts from an identical state at each checkpoint)."""
+    z, meta = harness.load_fixture(name)
+    n = 133
+    cfg = harness.make_cfg(name)
+    cfg.env.num_envs = n
+    meta = dict(meta, num_envs=n)
+    from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+    from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+    cm = compile_model(resolve_model("", meta["robot"]))
+    terrain = harness.FixtureTerrain(z, meta, cfg) if "const_height_samples" in z.files else None
+    hs = z["const_height_samples"] if terrain else None
+    A = meta["num_dofs"]
+    most_contacts = 0
+    for warm in (2, 5, 9):
+        a, b = (harness.HipHandle(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), terrain=terrain, seed=7), hs) for _ in range(2))
+        lib = a.core.lib
+        try:
+            rng = np.random.default_rng(3)
+            lib.lg_debug_set_phys_pair(1)
+            for e in (a, b):
+                e.set_step_counter(0)
+                e.inject(0)
+                e.call("reset_all")
+            for t in range(warm):
+                act = rng.uniform(-2, 2, (n, A)).astype(np.float32)
+                a.step(act)
+                b.step(act)
+            for key in ("dof_state", "root_states", "torques"):
+                np.testing.assert_array_equal(a.get(key), b.get(key), err_msg=f"warm-up {warm} {key}")
+            a.call("simulate")
+            lib.lg_debug_set_phys_pair(0)
+            b.call("simulate")
+            lib.lg_debug_set_phys_pair(1)
+            most_contacts = max(most_contacts, int((np.abs(a.get("contact_forces")).sum(-1) > 1.0).sum()))
+            for key in ("dof_state", "root_states", "contact_forces"):
+                x, y = a.get(key).astype(np.float64), b.get(key).astype(np.float64)
+                scale = max(1.0, float(np.abs(y).max()))
+                bad = np.abs(x - y) > 2e-5 * scale + 2e-5 * np.abs(y)
+                assert bad.mean() < 1e-3, (name, warm, key, float(np.abs(x - y).max()), scale, float(bad.mean()))
+        finally:
+            lib.lg_debug_set_phys_pair(1)
+            a.close()
+            b.close()
+    assert most_contacts >= n // 4, (name, most_contacts)             # the comparison was not of free flight only
+
+
 @pytest.mark.parametrize("name", ["a1", "cassie"])
 def test_joint_limit_constraints_match_oracle(name, oracle_built):
     """Joint-limit constraints of the physics (URDF lower/upper): free flight, joints driven into their stops --
