@@ -95,25 +95,29 @@ def time_iterations(runner, steps, warmup, world):
     return el, t_roll * steps
 
 
-def gemm_roofline(runner, hidden, reps=8):
-    """GEMM group of one minibatch (forward + backward of actor and critic: split-bf16 k_gemm launches
-    plus gather/loss), timed live with HIP events on the launch stream; algorithmic (fp32) FLOPs =
-    2 * MACs * rows * 3.  The kernels compute fp32-accurate products as 6 bf16 MFMAs
-    per 32x32x16 block, so the ceiling is the bf16 dense peak / 6; the fp32-input MFMA peak (what a
-    v_mfma_f32_32x32x2_f32 kernel is bounded by) is reported beside it."""
+def gemm_roofline(runner, hidden):
+    """GEMM group of one minibatch (forward + head + backward of actor and critic: everything lg_ppo_minibatch_backward
+    launches), timed live with HIP events on the launch stream INSIDE a real update -- begin_update, then epochs x minibatches
+    of {backward, optimiser step} as HipPPO.update() runs them, the events bracketing each backward (the optimiser step, which
+    also gathers the next minibatch, is outside the brackets; the first minibatch of the update, which gathers for itself, is
+    left out of the mean).  Algorithmic (fp32) FLOPs = 2 * MACs * rows * 3.  The kernels compute
+    fp32-accurate products as 6 bf16 MFMAs per 32x32x16 block, so the ceiling is the bf16 dense peak / 6; the fp32-input MFMA
+    peak (what a v_mfma_f32_32x32x2_f32 kernel is bounded by) is reported beside it."""
     ppo = runner.ppo
     R = ppo.T * ppo.N // ppo.cfg.num_mini_batches
     ppo._call("begin_update")
-    ppo._call("minibatch_backward", 0, 0)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for k in range(reps):
-        ppo._call("minibatch_backward", 0, k % ppo.cfg.num_mini_batches)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    pairs = []
+    for epoch in range(ppo.cfg.num_epochs):
+        for mb in range(ppo.cfg.num_mini_batches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ppo._call("minibatch_backward", epoch, mb)
+            e1.record()
+            ppo._call("minibatch_step")
+            pairs.append((e0, e1))
     ppo._call("end_update")
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in pairs[1:]) / (len(pairs) - 1)
     flops = 2.0 * macs_per_sample(ppo.O, list(hidden), ppo.A) * R * 3.0
     n_launch = (len(hidden) + 1) * 3 - 1          # fwd + dW per layer, dX for all but the first (actor+critic batched on grid.z)
     ach = flops / (ms * 1e-3) / 1e12

@@ -62,7 +62,7 @@ mb = names[gi[0]:gi[1]]
 si = window([i for i, n in enumerate(names) if "k_substeps" in n], ["k_post_step", "k_mlp_fwd"])
 st = names[si[0]:si[1]]                         # one policy step: substeps .. act of the next
 kib = lambda n: (2.0 * sum(fetch[n]) / len(fetch[n]) if n in fetch else 0.0) + (sum(write[n]) / len(write[n]) if n in write else 0.0)
-group = [n for n in mb if "k_gemm" in n or n.startswith("k_loss") or "k_head" in n] + ["k_gather4(PpoDev, int)"]
+group = [n for n in mb if "k_gemm" in n or n.startswith("k_loss") or "k_head" in n]      # what lg_ppo_minibatch_backward launches inside an update
 envk = [n for n in st if "k_substeps" in n or "k_post_step" in n or "k_finalize" in n]
 out = {"policy_hidden": [512, 256, 128],
        "gemm_group_bytes_per_minibatch": round(1024.0 * sum(kib(n) for n in group)),
