@@ -97,14 +97,14 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
 // The control loop of LeggedRobot.step (LR:86-96): clip the actions, then `iters` x {torque law, physics substep} with
 // the robot state (root, q, qd), the actuator-net state (h, c of both layers) and the model constants resident in
 // registers / LDS for the whole loop -- read once and written once per env step instead of once per substep, and 1 launch
-// instead of 1 + 2 x decimation.  Block = 4 waves = 64/L environments.  Wave 0 runs the physics (lane = (env, leg),
-// lg_physics.h).  All 256 lanes run the actuator net (8 lanes per (env, joint) row, 2J rounds per substep, the state of
-// each round in VGPRs); PD laws are evaluated by the physics lanes for their own joints.  q, qd and tau cross between the
-// two lane maps through LDS.
+// instead of 1 + 2 x decimation.  Block = 4 waves = 64/L environments.  Waves 0 and 1 run the physics, two lanes per
+// (env, leg) (lg_physics_pair.h; PAIR = false: wave 0 alone, one lane per (env, leg), lg_physics.h).  All 256 lanes run the
+// actuator net (8 lanes per (env, joint) row, 2J rounds per substep, the state of each round in VGPRs); PD laws are evaluated
+// by the physics lanes for their own joints.  q, qd and tau cross between the two lane maps through LDS.
 //
 // The operator-level entry points run THE SAME KERNEL with one stage switched off: lg_compute_torques = torque stage only
 // (LG_RUN_TORQUES, one iteration), lg_simulate = physics stage only with the torques read from the buffer (LG_RUN_PHYSICS).
-// One instance of the torque code and one of physics_lane serve all three, so lg_step equals the launch-per-substep
+// One instance of the torque code and one of the physics serve all three, so lg_step equals the launch-per-substep
 // sequence bit for bit (fp32 loads/stores between launches are exact; tests/test_hip_env.py asserts equality).
 #define LG_RUN_TORQUES 1
 #define LG_RUN_PHYSICS 2
