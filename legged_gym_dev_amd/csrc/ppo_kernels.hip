@@ -1385,7 +1385,8 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
     const int nout = actor ? A : 1;
     __shared__ float x[HEAD_ROWS * LDX];
     __shared__ float w[MA * H3];
-    __shared__ float outs[HEAD_ROWS][MA + 1], douts[HEAD_ROWS][MA + 1];
+    __shared__ float outs[HEAD_ROWS][MA + 1];
+    __shared__ __attribute__((aligned(16))) float douts[HEAD_ROWS][MA + 4];   // rows of 20 floats: the backward reads them as four b128
     __shared__ float red[2 * MA + 4], s_so2[MA], s_i2s2[MA], s_is2[MA], s_is[MA], s_lgs[MA], s_klc[MA];
     if (tid < MA) {
         const float sg = tid < A ? P.params[P.off_std + tid] : 1.f, so = tid < A ? P.st_sigma[tid] : 1.f;
@@ -1522,11 +1523,16 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
                 const float xv = x[r * LDX + c];
                 float g = 0.f;
                 if (actor) {
+                    float dmv[MA];
+#pragma unroll
+                    for (int a4 = 0; a4 < MA / 4; ++a4) {
+                        const float4 t = reinterpret_cast<const float4 *>(douts[r])[a4];
+                        dmv[4 * a4] = t.x; dmv[4 * a4 + 1] = t.y; dmv[4 * a4 + 2] = t.z; dmv[4 * a4 + 3] = t.w;
+                    }
 #pragma unroll
                     for (int a = 0; a < MA; ++a) {
-                        const float dm = douts[r][a];
-                        g += dm * wcol[a];
-                        dw[a] += dm * xv;
+                        g += dmv[a] * wcol[a];
+                        dw[a] += dmv[a] * xv;
                     }
                 } else {
                     const float dv = douts[r][0];
@@ -1539,29 +1545,30 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
             }
         }
     }
+    // the per-row sums of the loss lanes (wave 0), transposed through LDS: lane r writes its 36 partials as column r, thread k then
+    // adds the 64 entries of row k.  (A butterfly of 36 x 6 cross-lane shuffles on one wave took a third of this kernel.)
+    float *ptmp = x + (MA + 1) * NH * H3;                   // behind the [MA + 1][NH][H3] block that `acc` reuses below
+    static_assert((MA + 1) * NH * H3 + (2 * MA + 4) * HEAD_ROWS <= HEAD_ROWS * LDX, "partials fit behind acc in the tile buffer");
+    __syncthreads();                                        // every wave is done with the tile
     if (tid < HEAD_ROWS) {
 #pragma unroll
-        for (int k = 0; k < 2 * MA + 4; ++k) {
-            if (k >= 2 * MA || (k % MA) < A) {
-                float v = part[k];
-#pragma unroll
-                for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-                if (tid == 0) red[k] = v;
-            }
-        }
+        for (int k = 0; k < 2 * MA + 4; ++k) ptmp[k * HEAD_ROWS + tid] = part[k];
     }
     // Sums over the rows of this workgroup leave through a scratch row, not through atomics: 768 workgroups adding into the
     // same few dozen addresses serialise in L2 (24 us of this kernel's 46 were that queue).  k_head_finish folds the rows.
     float *__restrict__ prow = P.head_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * HEAD_PART_STRIDE(H3);
     float *acc = x;                                         // reuse the tile buffer: [MA + 1][NH][H3]
-    __syncthreads();
-    if (tid < 2 * MA + 4) prow[(MA + 1) * H3 + tid] = red[tid];
     if (half < NH) {
 #pragma unroll
         for (int a = 0; a < MA; ++a) acc[(a * NH + half) * H3 + c] = dw[a];
         acc[(MA * NH + half) * H3 + c] = db_prev;
     }
     __syncthreads();
+    if (tid < 2 * MA + 4) {
+        float v = 0.f;
+        for (int r = 0; r < HEAD_ROWS; ++r) v += ptmp[tid * HEAD_ROWS + r];
+        prow[(MA + 1) * H3 + tid] = v;
+    }
     for (int i = tid; i < (MA + 1) * H3; i += 256) {
         const int q = i / H3, cc = i % H3;
         float v = 0.f;
