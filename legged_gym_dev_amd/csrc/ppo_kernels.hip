@@ -1755,7 +1755,11 @@ int ppok_step(const PpoDev *P, int par, const PpoDev *G, int gather_mb, hipStrea
     const bool g4 = gather_mb >= 0 && (P->O & 3) == 0 && (P->A & 3) == 0 && (P->OC & 3) == 0;
     const int gblocks = g4 ? (P->mb_rows * 32 + 255) / 256 : 0;
     hipLaunchKernelGGL(k_opt_prepare, dim3(128 + gblocks), dim3(256), 0, s, *P, par, 128, g4 ? *G : *P, gather_mb);
-    hipLaunchKernelGGL(k_opt_adam, dim3(256), dim3(256), 0, s, *P, par);
+    // one parameter per thread: the per-parameter chain (4 loads, Adam, 4 stores + the three plane stores through pl_dest) is a
+    // memory round trip that a grid-stride loop repeats serially (6 x for [512,256,128] on 256 workgroups: 12.2 us; 8.9 us on 1024, 10.2 on 2048)
+    static const int adam_max = getenv("LG_ADAM_WGS") ? atoi(getenv("LG_ADAM_WGS")) : 1024;
+    const long want = (P->num_params + 255) / 256;
+    hipLaunchKernelGGL(k_opt_adam, dim3((unsigned)(want < adam_max ? (want > 0 ? want : 1) : adam_max)), dim3(256), 0, s, *P, par);
     return g4 ? 1 : 0;
 }
 }
