@@ -1325,22 +1325,18 @@ __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__res
             }
         }
     }
-    // ---- flush: loss partials (wave 0), then column accumulators reduced over the NH row groups through LDS
+    // ---- flush: loss partials of the row lanes (wave 0) transposed through LDS (lane r writes column r, thread k adds row k:
+    // a 36 x 6 shuffle butterfly on one wave is several times slower), then column accumulators reduced over the NH row groups
+    __shared__ float ptmp[(2 * MA + 4) * HEAD_ROWS];
     if (tid < HEAD_ROWS) {
 #pragma unroll
-        for (int k = 0; k < 2 * MA + 4; ++k) {
-            if (k >= 2 * MA || (k % MA) < A) {
-                float v = part[k];
-#pragma unroll
-                for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-                if (tid == 0) red[k] = v;
-            }
-        }
+        for (int k = 0; k < 2 * MA + 4; ++k) ptmp[k * HEAD_ROWS + tid] = part[k];
     }
     __syncthreads();
     if (tid < 2 * MA + 4 && (tid >= 2 * MA || (tid % MA) < A)) {
         const int k = tid;
-        const float v = red[k];
+        float v = 0.f;
+        for (int r = 0; r < HEAD_ROWS; ++r) v += ptmp[k * HEAD_ROWS + r];
         if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
         else if (k < 2 * MA) atomicAdd(&P.grads[b_a + (k - MA)], v);
         else if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
