@@ -139,3 +139,14 @@ def test_trajectory_dataset_rollout():
             np.testing.assert_array_equal(r["z"][i, t + 1], r["pz_x"][i, t + 1])
     finally:
         env.close()
+
+
+@pytest.mark.parametrize("case", [("anymal_c_flat", 1000, [512, 256, 128]), ("cassie", 777, [512, 256, 128]), ("anymal_c_flat", 7, [64, 32]),
+                                  ("anymal_c_flat_trajectory", 1234, [512, 256, 128])])
+def test_sizes_off_every_tile_grid(case):
+    """Env counts that are a multiple of no tile (control loop: 16 / 32 envs per workgroup; post-step: 16; one-launch act: 32
+    rows; minibatch rows off the 128-row GEMM and 64-row head grids; fewer envs than action dimensions) through the product
+    runner for two PPO iterations: finite state and parameters, no physics fault, parameters moved (tools/size_sweep.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import size_sweep
+    size_sweep.run(*case)
