@@ -226,6 +226,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 }
 // (x0, x1) -> packed bf16 pairs of the three split terms
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l) {
+#ifdef LG_EXP_NOSPLIT                                              // timing experiment only (make exp): what the split arithmetic costs
+    h = __float_as_uint(x0); m = __float_as_uint(x1); l = h ^ m;
+    return;
+#endif
     typedef float f32x2 __attribute__((ext_vector_type(2)));      // v_pk_add_f32: both remainders in one instruction
     h = cvt_pk_bf16(x0, x1);
     f32x2 r = f32x2{x0, x1} - f32x2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
