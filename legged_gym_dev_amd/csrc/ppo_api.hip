@@ -377,6 +377,7 @@ int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0
 int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
 int lg_ppo_debug_set_overlap(lg_ppo *p, int v) { p->overlap = v; return 0; }
 int lg_ppo_debug_set_fused_act(lg_ppo *p, int v) { p->fused_act = v && p->mlp.wfrag; return 0; }
+int lg_ppo_debug_get_fused_act(lg_ppo *p) { return p->fused_act; }          // 1: lg_ppo_act runs the one-launch forward for this shape
 int lg_ppo_debug_set_act_count(lg_ppo *p, long long v) { p->act_count = v; return 0; }   // replay the same Philox draws (tests)
 
 // entries: std, then per net per layer (W, b).  offsets[i]; shapes[2i] = rows, shapes[2i+1] = cols (0 for vectors)

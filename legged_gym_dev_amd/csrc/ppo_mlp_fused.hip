@@ -57,6 +57,7 @@ __device__ __forceinline__ float mlp_act(int code, float v) {
 #endif
 #define MLP_NT (64 * MLP_NW)
 #define MLP_KMAX 512
+__host__ __device__ __forceinline__ constexpr int mlp_kpad(int K) { return (K + 15) & ~15; }
 // Weight image of this kernel ("fragment order", built by k_mlp_frag_build from the fp32 parameters once per rollout): for
 // layer (z, l), column tile t (32 outputs) and k-step ks (16 inputs) the three planes h, m, l are 1 KB blocks
 //      frag_off[z][l] + ((t * K/16 + ks) * 3 + plane) * 512 + lane * 8 + j   =   plane of W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + j]
@@ -80,7 +81,9 @@ __device__ __forceinline__ BFrag mlp_load_frag(const uint16_t *__restrict__ wf, 
 template <int CT, int S, int ACT>
 __device__ __forceinline__ void mlp_layer(const MlpArgs &g, int z, int l, const float *__restrict__ cur, float *__restrict__ nxt, int row0,
                                           int wave, int t0, int li, int lk) {
-    const int K = g.dims[z][l], N = g.dims[z][l + 1], ld = K + 4, ldo = N + 4, nks = K / 16, nkb = (nks + S - 1) / S;
+    // K: the layer's input width rounded up to whole k-steps (only an observation width can be off the grid: 235 rough terrain,
+    // 169 Cassie, 65 trajectory task; the pad columns are zero in the LDS image and in the weight image)
+    const int K = mlp_kpad(g.dims[z][l]), N = g.dims[z][l + 1], ld = K + 4, ldo = N + 4, nks = K / 16, nkb = (nks + S - 1) / S;
     const int lane = li + 32 * lk;
     const bool head = l == g.nl - 1;
     const uint16_t *__restrict__ wf = g.wfrag + g.frag_off[z][l];
@@ -172,7 +175,7 @@ __device__ __forceinline__ void mlp_layer_tiles(const MlpArgs &g, int z, int l, 
 __global__ void __launch_bounds__(256) k_mlp_frag_build(MlpArgs g, uint16_t *__restrict__ wf) {
     for (int z = 0; z < 2; ++z)
         for (int l = 0; l < g.nl; ++l) {
-            const int K = g.dims[z][l], N = g.dims[z][l + 1], nks = K / 16, tiles = (N + 31) / 32;
+            const int K = g.dims[z][l], N = g.dims[z][l + 1], nks = mlp_kpad(K) / 16, tiles = (N + 31) / 32;
             const float *__restrict__ W = g.params + g.w_off[z][l];
             uint16_t *__restrict__ dst = wf + g.frag_off[z][l];
             const int total = tiles * nks * 64;                       // (tile, ks, lane)
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256) k_mlp_frag_build(MlpArgs g, uint16_t *__r
                 const int n = tile * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5);
                 float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = n < N ? W[(size_t)n * K + k + j] : 0.f;
+                for (int j = 0; j < 8; ++j) x[j] = (n < N && k + j < K) ? W[(size_t)n * K + min(k + j, K - 1)] : 0.f;
                 bf16x8 h, m, lo;
                 mlp_split8(x, h, m, lo);
                 uint16_t *q = dst + ((size_t)(tile * nks + ks) * 3) * 512 + lane * 8;
@@ -207,7 +210,8 @@ __global__ void __launch_bounds__(MLP_NT, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
 #define MSTAMP() do { } while (0)
 #endif
     {   // observations of the 32 rows -> LDS (rows past M read the last row: computed, never stored)
-        const int K = g.dims[z][0], ld = K + 4;
+        const int K = g.dims[z][0], Kp = mlp_kpad(K), ld = Kp + 4;
+        for (int i = tid; i < MLP_ROWS * (Kp - K); i += MLP_NT) cur[(i / (Kp - K)) * ld + K + i % (Kp - K)] = 0.f;   // pad columns
         for (int i = tid; i < MLP_ROWS * K; i += MLP_NT) {
             const int r = i / K, k = i - r * K;
             const int gr = min(row0 + r, g.M - 1);
@@ -276,13 +280,13 @@ extern "C" int ppok_mlp_supported(const MlpArgs *g) {
     for (int z = 0; z < 2; ++z)
         for (int l = 0; l < g->nl; ++l) {
             const int K = g->dims[z][l], N = g->dims[z][l + 1];
-            if (K % 16 || K > MLP_KMAX || K < 16) return -1;
+            if ((l > 0 && K % 16) || mlp_kpad(K) > MLP_KMAX || K < 1) return -1;
             if (l < g->nl - 1 && (N % 32 || N > MLP_KMAX)) return -1;
         }
     return 0;
 }
 // bf16 elements of the fragment-order image of layer (K inputs, N outputs)
-extern "C" int64_t ppok_mlp_frag_elems(int K, int N) { return (int64_t)((N + 31) / 32) * 32 * K * 3; }
+extern "C" int64_t ppok_mlp_frag_elems(int K, int N) { return (int64_t)((N + 31) / 32) * 32 * mlp_kpad(K) * 3; }
 extern "C" void ppok_mlp_frag_build(const MlpArgs *g, hipStream_t s) {
     hipLaunchKernelGGL(k_mlp_frag_build, dim3(256), dim3(256), 0, s, *g, const_cast<uint16_t *>(g->wfrag));
 }

@@ -67,12 +67,17 @@ def test_act_matches_torch(O, hidden):
     hip.close()
 
 
-def test_one_launch_act_equals_per_layer_act():
+@pytest.mark.parametrize("O", [48, 235, 169, 65])
+def test_one_launch_act_equals_per_layer_act(O):
     """lg_ppo_act as ONE launch (fragment-order weights, sampling + transition store in the epilogue: ppo_mlp_fused.hip) against
     the per-layer GEMMs + k_act_sample on the same learner: sampled actions, log-probs, values and the stored transition.
-    Philox noise (not injected): both paths draw the same stream.  Means / values go through differently tiled fp32 sums."""
-    N, O, A, T = 333, 48, 12, 3
+    Philox noise (not injected): both paths draw the same stream.  Means / values go through differently tiled fp32 sums.
+    Observation widths of the four tasks: 48 flat, 235 rough terrain, 169 Cassie, 65 trajectory task -- the last three are not
+    whole k-steps of 16 (zero pad columns in the LDS image and in the weight image)."""
+    N, A, T = 333, 12, 3
     hip, _, _ = _make(N, O, A, T)
+    hip.lib.lg_ppo_debug_set_fused_act(hip.ctx, 1)
+    assert hip.lib.lg_ppo_debug_get_fused_act(hip.ctx) == 1, "the one-launch forward must cover this shape"
     g = torch.Generator(device="cuda").manual_seed(5)
     obs = [torch.randn(N, O, device="cuda", generator=g) for _ in range(T)]
     got = []
