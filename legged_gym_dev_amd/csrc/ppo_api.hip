@@ -40,6 +40,7 @@ struct Net {
     int dims[LG_PPO_MAX_LAYERS + 1];         // dims[0] = input, dims[nl] = output
     int64_t w_off[LG_PPO_MAX_LAYERS], b_off[LG_PPO_MAX_LAYERS];
     int64_t pl_off[LG_PPO_MAX_LAYERS];       // offset of this layer's weight matrix inside a bf16 plane (multiple of 8)
+    int pl_ld0;                              // row length of W_0's plane image: dims[0] rounded up to 8 (pad columns zero)
     float *act[LG_PPO_MAX_LAYERS + 1];       // act[l], l >= 1: output of layer l-1 (workspace, Mmax rows)
     float *dz[LG_PPO_MAX_LAYERS + 1];        // gradient wrt act[l] pre-activation
 };
@@ -100,8 +101,11 @@ static int launch_ok() {
 }
 
 // forward of the selected nets on M rows.  in[z] = input of net z.  mask bit z selects the net.
-static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask, int skip_head = 0, bool planes = false) {
+// in_pad: the inputs are the minibatch gathers, rows padded to a multiple of 8 floats (PpoDev::Op / OCp); otherwise rows of dims[0]
+static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask, int skip_head = 0, bool planes = false,
+                    bool in_pad = false) {
     const float *in[2] = {in0, in1};
+    const int in_ld[2] = {in_pad ? p->dev.Op : p->net[0].dims[0], in_pad ? p->dev.OCp : p->net[1].dims[0]};
     int sel[2], nz = 0;
     for (int z = 0; z < 2; ++z) if (mask & (1 << z)) sel[nz++] = z;
     const int nl = p->net[sel[0]].nl;
@@ -116,7 +120,10 @@ static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int ma
             g.Bpl[k] = planes ? p->dev.wpl + n.pl_off[l] : nullptr;      // valid only inside an update (lg_ppo_begin_update syncs them)
             g.C[k] = n.act[l + 1];
             g.M[k] = M; g.N[k] = n.dims[l + 1]; g.K[k] = n.dims[l];
-            g.lda[k] = n.dims[l]; g.ldb[k] = n.dims[l]; g.ldc[k] = n.dims[l + 1];
+            g.lda[k] = l == 0 ? in_ld[sel[k]] : n.dims[l]; g.ldb[k] = n.dims[l]; g.ldc[k] = n.dims[l + 1];
+            // W_0's plane image has rows as long as the padded gather rows: with both padded the plane path reduces over whole chunks
+            if (l == 0 && in_pad && planes && n.pl_ld0 != n.dims[0]) { g.Kpl[k] = n.pl_ld0; g.ldbpl[k] = n.pl_ld0; }
+            else if (l == 0 && n.pl_ld0 != n.dims[0]) g.Bpl[k] = nullptr;   // unpadded input against padded plane rows: fp32 operand
         }
         g.elu = l < nl - 1 ? p->act_code : 0;
         g.pl_stride = p->dev.pl_stride;
@@ -162,6 +169,11 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
             g.B[z] = l == 0 ? in[z] : n.act[l]; g.ldb[z] = n.dims[l];
             g.C[z] = p->dev.grads + n.w_off[l]; g.ldc[z] = n.dims[l];
             g.M[z] = n.dims[l + 1]; g.N[z] = n.dims[l]; g.K[z] = M;
+            if (l == 0) {                            // the minibatch gathers: padded rows, the pad columns computed but not stored
+                const int ldp = z == 0 ? p->dev.Op : p->dev.OCp;
+                g.ldb[z] = ldp;
+                if (ldp != n.dims[0]) { g.N[z] = ldp; g.nstore[z] = n.dims[0]; }
+            }
             const int tile = (g.M[z] > 64 && g.N[z] > 64) ? 128 : 64;
             long t = (long)((g.M[z] + tile - 1) / tile) * ((g.N[z] + tile - 1) / tile);
             tiles = t > tiles ? t : tiles;
@@ -275,6 +287,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         }
     }
     d.num_params = off;
+    int seg_ld[LG_PPO_MAX_SEG];
     {   // bf16 plane layout: one segment per weight matrix, 16-byte aligned
         int64_t po = 0;
         d.nseg = 0;
@@ -284,14 +297,19 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
                 n.pl_off[l] = po;
                 d.seg_off[d.nseg] = n.w_off[l]; d.seg_pl[d.nseg] = po;
                 d.seg_rows[d.nseg] = n.dims[l + 1]; d.seg_cols[d.nseg] = n.dims[l];
+                // rows of the first layer's image padded to whole 16-byte chunks (the observation width need not be one)
+                const int ld = l == 0 ? (n.dims[0] + 7) / 8 * 8 : n.dims[l];
+                if (l == 0) n.pl_ld0 = ld;
+                seg_ld[d.nseg] = ld;
                 ++d.nseg;
-                po += ((int64_t)n.dims[l + 1] * n.dims[l] + 7) / 8 * 8;
+                po += ((int64_t)n.dims[l + 1] * ld + 7) / 8 * 8;
             }
         d.pl_stride = po;
     }
     d.off_bias_actor_head = (int)p->net[0].b_off[p->net[0].nl - 1];
     d.off_bias_critic_head = (int)p->net[1].b_off[p->net[1].nl - 1];
     d.N = N; d.T = T; d.A = A; d.O = O; d.OC = OC; d.mb_rows = R;
+    d.Op = (O + 7) / 8 * 8; d.OCp = (OC + 7) / 8 * 8;
     d.world = cfg->world_size > 0 ? cfg->world_size : 1;
     d.env_offset = 0;
     d.adaptive = cfg->adaptive_schedule; d.clipped_value = cfg->use_clipped_value_loss;
@@ -306,7 +324,8 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         PA(d.pl_dest, (size_t)off + 2);
         std::vector<int32_t> dest((size_t)off + 2, -1);
         for (int sg = 0; sg < d.nseg; ++sg)
-            for (int64_t e = 0; e < (int64_t)d.seg_rows[sg] * d.seg_cols[sg]; ++e) dest[d.seg_off[sg] + e] = (int32_t)(d.seg_pl[sg] + e);
+            for (int64_t e = 0; e < (int64_t)d.seg_rows[sg] * d.seg_cols[sg]; ++e)
+                dest[d.seg_off[sg] + e] = (int32_t)(d.seg_pl[sg] + (e / d.seg_cols[sg]) * seg_ld[sg] + e % d.seg_cols[sg]);
         (void)hipMemcpy(d.pl_dest, dest.data(), dest.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     }
     const size_t TN = (size_t)T * N;
@@ -318,8 +337,8 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     PA(d.stats, 8); PA(d.loss_acc, 4); PA(d.noise, (size_t)N * A); PA(d.perm, TN); PA(d.adv_partial, 4);
     for (int k = 0; k < 2; ++k) {
         lg_ppo::MbSet &m = p->mbset[k];
-        PA(m.obs, (size_t)R * O);
-        if (cfg->num_critic_obs > 0) PA(m.critic_obs, (size_t)R * OC); else m.critic_obs = m.obs;
+        PA(m.obs, (size_t)R * d.Op);                // pad columns: zeroed here, never written
+        if (cfg->num_critic_obs > 0) PA(m.critic_obs, (size_t)R * d.OCp); else m.critic_obs = m.obs;
         PA(m.actions, (size_t)R * A); PA(m.mu, (size_t)R * A); PA(m.scalars, (size_t)R * 4);
     }
     p->mb_cur = 0; p->mb_ready = -1; p->mb_last = -1;
@@ -482,7 +501,7 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     // long pole (profiles/r02_timelines.txt) it is 9 us faster than head GEMM + k_loss + two head-gradient GEMMs (A/B on one box)
     static const int fuse128 = getenv("LG_HEAD_FUSE128") ? atoi(getenv("LG_HEAD_FUSE128")) : 1;
     const bool fuse = p->act_code == 1 && nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32 || (H3 == 128 && fuse128));
-    forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true);
+    forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true, true);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],
                         nc.w_off[nl - 1], nc.b_off[nl - 1], na.b_off[nl - 2], nc.b_off[nl - 2], p->stream);

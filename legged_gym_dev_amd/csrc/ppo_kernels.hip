@@ -771,7 +771,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm
         body(k0, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
         if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
     }
-    gemm_epilogue<2, TM, TN, BM, BN, 1>(g, z, M, N, m0, n0, wm, wn, li, lk, ldc, acc);
+    // nstore: columns past it are products with the zero pad columns of the padded observations -- computed, not stored
+    gemm_epilogue<2, TM, TN, BM, BN, 1>(g, z, M, g.nstore[z] ? g.nstore[z] : N, m0, n0, wm, wn, li, lk, ldc, acc);
 }
 
 extern "C" void ppok_debug_set_xcd_remap(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_remap), &v, sizeof(int)); }
@@ -852,7 +853,12 @@ static bool planes_t_ok(const GemmArgs &g, int nz) {
 // whichever path is eligible is taken.  Forward: the planes are the reduction-contiguous operand.  Input gradient: the
 // SAME planes, reduced over their rows through the transposing LDS read (no second image of W^T to keep current).
 extern "C" void ppok_gemm_fwd(const GemmArgs *g, int nz, hipStream_t s) {
-    if (planes_ok(*g, nz)) launch_gemm_pl<0>(*g, nz, s);
+    GemmArgs gp = *g;                          // the plane path's view of the reduction dimension (padded first layer, ppo_device.h)
+    for (int z = 0; z < nz; ++z) {
+        if (g->Kpl[z]) gp.K[z] = g->Kpl[z];
+        if (g->ldbpl[z]) gp.ldb[z] = g->ldbpl[z];
+    }
+    if (planes_ok(gp, nz)) launch_gemm_pl<0>(gp, nz, s);
     else launch_gemm<true, true, 0>(*g, nz, 1, s);
 }
 extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s) {
@@ -860,7 +866,12 @@ extern "C" void ppok_gemm_dx(const GemmArgs *g, int nz, hipStream_t s) {
     else launch_gemm<true, false, 1>(*g, nz, 1, s);
 }
 extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t s) {
-    if (!(g_gemm_dw_t && g_gemm_x6)) { launch_gemm<false, false, 2>(*g, nz, splits, s); return; }
+    if (!(g_gemm_dw_t && g_gemm_x6)) {         // k_gemm's store guard is its N: compute the true width only
+        GemmArgs gt = *g;
+        for (int z = 0; z < nz; ++z) if (g->nstore[z]) gt.N[z] = g->nstore[z];
+        launch_gemm<false, false, 2>(gt, nz, splits, s);
+        return;
+    }
     int maxM = 0, maxN = 0;
     for (int z = 0; z < nz; ++z) { maxM = g->M[z] > maxM ? g->M[z] : maxM; maxN = g->N[z] > maxN ? g->N[z] : maxN; }
     const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
@@ -1016,9 +1027,9 @@ __global__ void k_gather(PpoDev P, int mb) {
     const int r = blockIdx.x;
     if (r >= R) return;
     const int src = P.perm[(size_t)mb * R + r];
-    for (int k = threadIdx.x; k < O; k += blockDim.x) P.mb_obs[(size_t)r * O + k] = P.st_obs[(size_t)src * O + k];
+    for (int k = threadIdx.x; k < O; k += blockDim.x) P.mb_obs[(size_t)r * P.Op + k] = P.st_obs[(size_t)src * O + k];
     if (P.st_critic_obs != P.st_obs)
-        for (int k = threadIdx.x; k < P.OC; k += blockDim.x) P.mb_critic_obs[(size_t)r * P.OC + k] = P.st_critic_obs[(size_t)src * P.OC + k];
+        for (int k = threadIdx.x; k < P.OC; k += blockDim.x) P.mb_critic_obs[(size_t)r * P.OCp + k] = P.st_critic_obs[(size_t)src * P.OC + k];
     if ((int)threadIdx.x < A) {
         P.mb_actions[(size_t)r * A + threadIdx.x] = P.st_actions[(size_t)src * A + threadIdx.x];
         P.mb_mu[(size_t)r * A + threadIdx.x] = P.st_mu[(size_t)src * A + threadIdx.x];
@@ -1032,18 +1043,23 @@ __global__ void k_gather(PpoDev P, int mb) {
 }
 
 // same gather, 32 lanes per row moving 16 bytes each (obs, actions, mu as float4s; the four scalars as one float4):
-// used when O, OC and A are multiples of 4 (every pointer is then 16-byte aligned row by row)
+// used when A is a multiple of 4.  An observation width that is not (235 rough terrain, 169 Cassie, 65 trajectory task: the
+// storage rows are then not 16-byte aligned) is read a float per lane; the destination rows are Op / OCp long either way.
 __device__ __forceinline__ void gather4_block(const PpoDev &P, int mb, int vblock) {
-    const int R = P.mb_rows, A4 = P.A / 4, O4 = P.O / 4;
+    const int R = P.mb_rows, A4 = P.A / 4;
     const int gid = vblock * 256 + threadIdx.x;
     const int r = gid >> 5, j = gid & 31;
     if (r >= R) return;
     const int src = P.perm[(size_t)mb * R + r];
     const bool own_critic = P.st_critic_obs != P.st_obs;
-    const int OC4 = own_critic ? P.OC / 4 : 0;
+    const int O4 = (P.O & 3) ? 0 : P.O / 4, OC4 = (own_critic && !(P.OC & 3)) ? P.OC / 4 : 0;
+    if (P.O & 3)
+        for (int k = j; k < P.O; k += 32) P.mb_obs[(size_t)r * P.Op + k] = P.st_obs[(size_t)src * P.O + k];
+    if (own_critic && (P.OC & 3))
+        for (int k = j; k < P.OC; k += 32) P.mb_critic_obs[(size_t)r * P.OCp + k] = P.st_critic_obs[(size_t)src * P.OC + k];
     for (int k = j; k < O4 + OC4 + 2 * A4 + 1; k += 32) {
-        if (k < O4) reinterpret_cast<float4 *>(P.mb_obs)[(size_t)r * O4 + k] = reinterpret_cast<const float4 *>(P.st_obs)[(size_t)src * O4 + k];
-        else if (k < O4 + OC4) reinterpret_cast<float4 *>(P.mb_critic_obs)[(size_t)r * OC4 + (k - O4)] = reinterpret_cast<const float4 *>(P.st_critic_obs)[(size_t)src * OC4 + (k - O4)];
+        if (k < O4) reinterpret_cast<float4 *>(P.mb_obs)[(size_t)r * (P.Op / 4) + k] = reinterpret_cast<const float4 *>(P.st_obs)[(size_t)src * O4 + k];
+        else if (k < O4 + OC4) reinterpret_cast<float4 *>(P.mb_critic_obs)[(size_t)r * (P.OCp / 4) + (k - O4)] = reinterpret_cast<const float4 *>(P.st_critic_obs)[(size_t)src * OC4 + (k - O4)];
         else if (k < O4 + OC4 + A4) reinterpret_cast<float4 *>(P.mb_actions)[(size_t)r * A4 + (k - O4 - OC4)] = reinterpret_cast<const float4 *>(P.st_actions)[(size_t)src * A4 + (k - O4 - OC4)];
         else if (k < O4 + OC4 + 2 * A4) reinterpret_cast<float4 *>(P.mb_mu)[(size_t)r * A4 + (k - O4 - OC4 - A4)] = reinterpret_cast<const float4 *>(P.st_mu)[(size_t)src * A4 + (k - O4 - OC4 - A4)];
         else reinterpret_cast<float4 *>(P.mb_scalars)[r] = make_float4(P.st_values[src], P.st_returns[src], P.st_adv[src], P.st_log_prob[src]);
@@ -1720,7 +1736,7 @@ void ppok_randperm(const PpoDev *P, int n, uint64_t update_idx, hipStream_t s) {
     hipLaunchKernelGGL(k_randperm, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, bits / 2, update_idx);
 }
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s) {
-    if ((P->O & 3) == 0 && (P->A & 3) == 0 && (P->OC & 3) == 0)
+    if ((P->A & 3) == 0)
         hipLaunchKernelGGL(k_gather4, dim3((P->mb_rows * 32 + 255) / 256), dim3(256), 0, s, *P, mb);
     else
         hipLaunchKernelGGL(k_gather, dim3(P->mb_rows), dim3(64), 0, s, *P, mb);
@@ -1752,7 +1768,7 @@ void ppok_sync_planes(const PpoDev *P, hipStream_t s) { hipLaunchKernelGGL(k_syn
 // G / gather_mb: buffer set and index of a minibatch to gather beside the norm reduction (gather_mb < 0: none); returns
 // whether the gather was taken (the 16-byte row layout of k_gather4)
 int ppok_step(const PpoDev *P, int par, const PpoDev *G, int gather_mb, hipStream_t s) {
-    const bool g4 = gather_mb >= 0 && (P->O & 3) == 0 && (P->A & 3) == 0 && (P->OC & 3) == 0;
+    const bool g4 = gather_mb >= 0 && (P->A & 3) == 0;
     const int gblocks = g4 ? (P->mb_rows * 32 + 255) / 256 : 0;
     hipLaunchKernelGGL(k_opt_prepare, dim3(128 + gblocks), dim3(256), 0, s, *P, par, 128, g4 ? *G : *P, gather_mb);
     // one parameter per thread: the per-parameter chain (4 loads, Adam, 4 stores + the three plane stores through pl_dest) is a

@@ -112,8 +112,12 @@ def test_philox_sampling_is_standard_normal():
     hip.close()
 
 
-def test_returns_and_gradients_match_torch():
-    N, O, A, T = 512, 48, 12, 8
+@pytest.mark.parametrize("O", [48, 235, 169, 65])
+def test_returns_and_gradients_match_torch(O):
+    """O: the observation widths of the four tasks.  235, 169 and 65 are not multiples of 8: the minibatch gathers and the
+    first layer's weight planes then carry zero pad columns (rows of 240 / 176 / 72) and the first layer's weight gradient is
+    computed on the padded width and stored on the true one."""
+    N, A, T = 512, 12, 8
     hip, ac, pt = _make(N, O, A, T)
     g = torch.Generator(device="cuda").manual_seed(2)
     rec = _fill_rollout(hip, ac, T, N, O, A, g)
