@@ -642,18 +642,19 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
 
     // ---- phase H: height scan of the pre-reset pose (LR:356-357)
     if (c.measure_heights) {
-        // four scan points per lane and trip: their 12 height-sample gathers are independent and in flight together (one lane
+        // HU scan points per lane and trip: their 3 HU height-sample gathers are independent and in flight together (one lane
         // per point and trip exposed three dependent-latency round trips per trip to a lone wave)
-        for (int idx0 = tid; idx0 < nE * H; idx0 += 4 * LG_TILE_THREADS) {
-            float v[4];
+        constexpr int HU = 4;                                     // scan points per lane and trip (8: slower, 25.7 k vs 21.3 k cycles at 187 points)
+        for (int idx0 = tid; idx0 < nE * H; idx0 += HU * LG_TILE_THREADS) {
+            float v[HU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < HU; ++u) {
                 const int idx = min(idx0 + u * LG_TILE_THREADS, nE * H - 1);
                 const int e = env0 + idx / H, h = idx % H;
                 v[u] = c.terrain_type == 1 ? height_sample(P, P->buf.root_states + (size_t)e * 13, h) : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < HU; ++u) {
                 const int idx = idx0 + u * LG_TILE_THREADS;
                 if (idx < nE * H) P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H] = v[u];
             }
@@ -821,7 +822,14 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     // Segment by segment (frame block | joint positions | joint rates | actions | heights), four entries per lane and trip with
     // their operand loads issued together: one generic loop over all entries took a different branch -- and exposed one more
     // global-load latency to the lone wave -- for every kind of entry its 64 lanes happened to hold.
+    // Noise: slot s_noise + k of the env's Philox stream per entry.  One Philox evaluation yields the uniforms of four consecutive
+    // slots (philox_uniform4), so the noiseless entries are staged in LDS by the segment loops and a second pass walks the stream
+    // block by block: a quarter of the evaluations of one per entry (rough terrain: 235 entries x 16 envs per workgroup).
+    constexpr int OBS_LDS = 256;                                        // widest observation row staged (rough terrain: 235)
+    __shared__ float s_ob[TILE * OBS_LDS];
+    const bool stage = c.add_noise && O <= OBS_LDS;
     auto emit = [&](int i, int k, float v) {
+        if (stage) { s_ob[(i - env0) * OBS_LDS + k] = v; return; }
         if (c.add_noise) v += (2.0f * uni(P, i, s_noise + k, counter, inject) - 1.0f) * P->noise_vec[k];
         P->buf.obs[(size_t)i * O + k] = clampf(v, -c.clip_obs, c.clip_obs);
     };
@@ -862,6 +870,24 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
                 if (idx < nE * H) emit(env0 + idx / H, ob + 3 * A + idx % H, clampf(rz[u] - 0.5f - hv[u], -1.0f, 1.0f) * c.obs_scale_height);
             }
         }
+    if (stage) {
+        __syncthreads();
+        const int b0 = s_noise >> 2, nb = ((s_noise + O + 3) >> 2) - b0;  // Philox blocks that hold the noise slots
+        for (int idx = tid; idx < nE * nb; idx += LG_TILE_THREADS) {
+            const int e = idx / nb, b = b0 + idx % nb, i = env0 + e;
+            float u4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!inject) philox_uniform4(c.seed, (uint32_t)(c.env_offset + i), (uint64_t)counter, (uint32_t)b, u4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * b + r - s_noise;
+                if (k < 0 || k >= O) continue;
+                const float u = inject ? P->buf.inject_uniforms[(size_t)i * P->K + 4 * b + r] : u4[r];
+                float v = s_ob[e * OBS_LDS + k];
+                v += (2.0f * u - 1.0f) * P->noise_vec[k];
+                P->buf.obs[(size_t)i * O + k] = clampf(v, -c.clip_obs, c.clip_obs);
+            }
+        }
+    }
     for (int idx = tid; idx < nE * A; idx += LG_TILE_THREADS) {
         const size_t ij = (size_t)env0 * A + idx;
         P->buf.last_actions[ij] = P->buf.actions[ij];
