@@ -52,6 +52,17 @@ def snapshot(env, runner):
                 adv_mean=runner.ppo.t["stats"][6].cpu().numpy(), fault_total=t["fault_total"].cpu().numpy())
 
 
+def learn_with_first_snapshot(runner, iters):
+    """learn(iters) as learn(1) + learn(iters - 1); returns the parameters after the first iteration."""
+    runner.learn(1, init_at_random_ep_len=False)
+    torch.cuda.synchronize()
+    first = runner.ppo.t["params"][: runner.ppo.num_params].cpu().numpy()
+    if iters > 1:
+        runner.learn(iters - 1, init_at_random_ep_len=False)
+        torch.cuda.synchronize()
+    return first
+
+
 def main():
     outdir, task, n, iters = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -59,9 +70,8 @@ def main():
     torch.distributed.init_process_group("gloo")
     env, runner = build(task, n, rank, world)
     assert runner.world_size == world and runner.rank == rank
-    runner.learn(iters, init_at_random_ep_len=False)
-    torch.cuda.synchronize()
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **snapshot(env, runner))
+    first = learn_with_first_snapshot(runner, iters)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), params_it1=first, **snapshot(env, runner))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -88,12 +88,12 @@ def _emulate(task, n, iters, world=2):
     built = [w.build(task, n, r, world, comm=_ThreadComm(r, shared)) for r in range(world)]
     shared["phase"] = "learn"
     errs = []
+    firsts = [None] * world
 
     def learn(r):
         try:
             torch.cuda.set_device(0)
-            built[r][1].learn(iters, init_at_random_ep_len=False)
-            torch.cuda.synchronize()
+            firsts[r] = w.learn_with_first_snapshot(built[r][1], iters)
         except BaseException as e:          # noqa: BLE001
             errs.append(e)
             shared["barrier"].abort()
@@ -104,7 +104,7 @@ def _emulate(task, n, iters, world=2):
         t.join(600)
     if errs:
         raise errs[0]
-    snaps = [w.snapshot(*built[r]) for r in range(world)]
+    snaps = [dict(w.snapshot(*built[r]), params_it1=firsts[r]) for r in range(world)]
     for env, runner in built:
         env.close()
         runner.ppo.close()
@@ -133,16 +133,23 @@ def test_two_rank_runner_over_gloo(task, tmp_path):
     for r in range(2):                                    # the shards themselves are reproduced exactly
         for key in ("friction", "base_mass_delta", "env_origins"):
             np.testing.assert_array_equal(emu[r][key], ranks[r][key], err_msg=f"rank {r} {key}")
-    rel = np.linalg.norm(emu[0]["params"] - a["params"]) / np.linalg.norm(a["params"])
     # The kernels accumulate gradients, bias sums and loss statistics with float atomics, so two runs of the SAME code differ
-    # in the last bits of every gradient and contact dynamics amplify that over 48 policy steps.  The bar is therefore the
-    # run-to-run noise of the emulation itself (measured here by running it twice), with 2e-4 as the floor:
-    emu2 = _emulate(task, n, iters)
-    noise = np.linalg.norm(emu2[0]["params"] - emu[0]["params"]) / np.linalg.norm(a["params"])
-    assert rel < max(2e-4, 4.0 * noise), (rel, noise)
-    # element-wise: an Adam step on a near-zero gradient is a sign step of size lr, so allow 2 x lr absolute
+    # in the last bits of every gradient.  After ONE iteration (24 policy steps on identical parameters, 20 optimiser steps)
+    # that is all there is: process run and emulation agree to 1e-7 of the parameter norm (tools/diag_multi_rank_noise.py:
+    # 8e-8 .. 9e-8 between any two of three process runs and three emulations).
+    rel1 = np.linalg.norm(emu[0]["params_it1"] - a["params_it1"]) / np.linalg.norm(a["params_it1"])
+    assert rel1 < 1e-5, rel1
+    np.testing.assert_array_equal(a["params_it1"], b["params_it1"])
+    # The second rollout runs on parameters that differ by those 1e-7, and contact dynamics turn that into discrete events
+    # (a foot that touches down one substep later, a reset one step later): runs of the same kind then fall on branches
+    # 1.5e-4 .. 8.5e-4 apart and agree to 2e-6 .. 1e-5 inside a branch (same tool: process runs {0, 2} and {1}, emulations
+    # {0, 2} and {1}, process run 1 with emulation 1).  Emulation-vs-emulation spread is therefore no noise floor for this
+    # comparison; after two iterations only the order of magnitude is asserted, and element-wise that no parameter is further
+    # off than a few sign steps of Adam (a step on a near-zero gradient is lr * sign(g)).
+    rel2 = np.linalg.norm(emu[0]["params"] - a["params"]) / np.linalg.norm(a["params"])
+    assert rel2 < 5e-3, rel2
     d = np.abs(emu[0]["params"] - a["params"])
-    bad = d > 2e-4 * np.abs(a["params"]) + 2.0 * float(a["lr"]) + 8.0 * np.abs(emu2[0]["params"] - emu[0]["params"])
+    bad = d > 2e-4 * np.abs(a["params"]) + 4.0 * float(a["lr"])
     assert bad.mean() < 5e-3, bad.mean()
 
 
