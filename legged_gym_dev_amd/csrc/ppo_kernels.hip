@@ -1053,10 +1053,20 @@ __device__ __forceinline__ void gather4_block(const PpoDev &P, int mb, int vbloc
     const int src = P.perm[(size_t)mb * R + r];
     const bool own_critic = P.st_critic_obs != P.st_obs;
     const int O4 = (P.O & 3) ? 0 : P.O / 4, OC4 = (own_critic && !(P.OC & 3)) ? P.OC / 4 : 0;
-    if (P.O & 3)
-        for (int k = j; k < P.O; k += 32) P.mb_obs[(size_t)r * P.Op + k] = P.st_obs[(size_t)src * P.O + k];
-    if (own_critic && (P.OC & 3))
-        for (int k = j; k < P.OC; k += 32) P.mb_critic_obs[(size_t)r * P.OCp + k] = P.st_critic_obs[(size_t)src * P.OC + k];
+    // eight loads in flight per lane, then the stores (a load / store pair per trip is one L2 round trip per trip: the stores may
+    // alias the loads as far as the compiler knows)
+    auto row_copy = [&](const float *__restrict__ from, float *__restrict__ to, int n) {
+        for (int k0 = j; k0 < n; k0 += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = from[min(k0 + 32 * u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + 32 * u < n) to[k0 + 32 * u] = v[u];
+        }
+    };
+    if (P.O & 3) row_copy(P.st_obs + (size_t)src * P.O, P.mb_obs + (size_t)r * P.Op, P.O);
+    if (own_critic && (P.OC & 3)) row_copy(P.st_critic_obs + (size_t)src * P.OC, P.mb_critic_obs + (size_t)r * P.OCp, P.OC);
     for (int k = j; k < O4 + OC4 + 2 * A4 + 1; k += 32) {
         if (k < O4) reinterpret_cast<float4 *>(P.mb_obs)[(size_t)r * (P.Op / 4) + k] = reinterpret_cast<const float4 *>(P.st_obs)[(size_t)src * O4 + k];
         else if (k < O4 + OC4) reinterpret_cast<float4 *>(P.mb_critic_obs)[(size_t)r * (P.OCp / 4) + (k - O4)] = reinterpret_cast<const float4 *>(P.st_critic_obs)[(size_t)src * OC4 + (k - O4)];
