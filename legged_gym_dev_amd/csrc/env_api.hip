@@ -9,9 +9,7 @@ static thread_local std::string g_err;
 void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
-extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, int64_t counter,
-                            int inject, int init_done, hipStream_t s);
-extern "C" void lgk_post_tail(const DevParams *P, int N, int64_t counter, int inject, int traj, hipStream_t s);
+extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s);
 extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
 extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int N, int64_t counter, int inject, int init_done, int traj,
@@ -228,8 +226,7 @@ int lg_set_actions(lg_ctx *c, const float *actions) {
 }
 static int run_substeps(lg_ctx *c, const float *actions, int mode, int iters) {
     const lg_cfg &f = c->h.cfg;
-    if (lgk_substeps(c->d, actions, f.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg, f.use_actuator_net, mode, iters, c->step_counter,
-                     c->inject, c->init_done, c->stream)) {
+    if (lgk_substeps(c->d, actions, f.num_envs, c->h.model.num_legs, c->h.model.joints_per_leg, f.use_actuator_net, mode, iters, c->stream)) {
         g_err = "no control-loop kernel for this topology / actuator combination (have 4x3 PD, 4x3 actuator net, 2x6 PD)";
         return -4;
     }
@@ -264,25 +261,8 @@ int lg_debug_set_fused(int v) { g_fused_substeps = v; return 0; }
 extern "C" void lgk_debug_set_phys_pair(int v);
 int lg_debug_set_phys_pair(int v) { lgk_debug_set_phys_pair(v); return 0; }   // physics lane map: 1 pair-lane (default), 0 one lane per leg
 
-// LG_FUSED_POST=1: post_physics_step runs in the tail of the control-loop launch, workgroup by workgroup (k_substeps, LG_RUN_POST);
-// 0 (default): its own launch (k_post_step).  Same device code either way, results bit-identical (the GPU suite passes under both).
-// Measured NEUTRAL (rollout 4.24 / 4.26 ms fused vs 4.30 / 4.22 ms, profiles/r02_ab.txt): every workgroup's post-step is a latency
-// chain as long as the whole k_post_step launch, so the slowest workgroup still ends 17 us after its control loop -- the launch
-// boundary itself costs ~1 us.  Off by default: the separate launch keeps the two stages apart in the kernel trace.
-static int g_fused_post = -1;
-int lg_debug_set_fused_post(int v) { g_fused_post = v ? 1 : 0; return 0; }
 int lg_step(lg_ctx *c, const float *actions) {                  // legged_robot.py:80-104
     int rc;
-    if (g_fused_post < 0) { const char *e = getenv("LG_FUSED_POST"); g_fused_post = e ? (atoi(e) ? 1 : 0) : 0; }
-    if (g_fused_substeps && g_fused_post) {                     // one launch for the control loop + the per-env post-step
-        c->step_counter += 1;                                   // legged_robot.py:115
-        rc = run_substeps(c, actions, 7, c->h.cfg.decimation);
-        if (!rc) {
-            lgk_post_tail(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->h.cfg.traj.enabled, c->stream);
-            rc = chk_launch();
-        }
-        return rc;
-    }
     if (g_fused_substeps) {                                     // one launch for clip + decimation x {torques, physics}
         rc = run_substeps(c, actions, 3, c->h.cfg.decimation);
     } else {                                                    // launch per substep (A/B and debugging)

@@ -107,17 +107,14 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
 // One instance of the torque code and one of the physics serve all three, so lg_step equals the launch-per-substep
 // sequence bit for bit (fp32 loads/stores between launches are exact; tests/test_hip_env.py asserts equality).
 //
-// LG_RUN_POST (lg_step only): the workgroup goes on with post_physics_step for its own environments (post_step_tile, the body
-// of k_post_step) as soon as its control loop is done -- no launch boundary, and a workgroup with few contacts does not wait
-// for the slowest one of the grid before its rewards and observations are computed.
+// Measured and not kept: post_physics_step in the tail of this launch, each workgroup for its own environments (same device code,
+// bit-identical): neutral at 4096 envs (every workgroup's post-step is a latency chain as long as the whole k_post_step launch)
+// and it doubles this kernel's LDS footprint (75 -> 132 KB; Cassie 99 -> 156 KB), which takes away the second resident workgroup
+// per CU that larger env counts use.
 #define LG_RUN_TORQUES 1
 #define LG_RUN_PHYSICS 2
-#define LG_RUN_POST 4
-template <int TILE>
-__device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, const int env0, int64_t counter, int inject, int init_done);
 template <int L, int J, bool LSTM, bool PAIR>
-__global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters,
-                                                     int64_t counter, int inject, int init_done) {
+__global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
     constexpr int A = L * J, EPW = 64 / L, ROWS = EPW * A, NR = ROWS * 8 / 256;
     constexpr int PW = PAIR ? 2 : 1, LPE = PAIR ? 2 * L : L;    // physics waves of the block, physics lanes per env
     const lg_cfg &c = P->cfg;
@@ -295,13 +292,6 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     if ((tid & 63) == 0 && wave < 2 && blockIdx.x < 16)
         for (int k = 0; k < 16; ++k) P->dbg_cycles[(blockIdx.x * 2 + wave) * 16 + k] = pr.acc[k];
 #endif
-    if (mode & LG_RUN_POST) {
-        static_assert(LG_TILE_THREADS == 256, "the post-step tile runs on the control loop's workgroup");
-        for (int e = 0; e < EPW && env0 + e < N; e += 16) {      // workgroup-uniform
-            __syncthreads();                                      // the state stores above (and the previous tile's LDS) are done
-            post_step_tile<16>(P, env0 + e, counter, inject, init_done);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,9 +612,7 @@ __device__ __forceinline__ float height_sample(const DevParams *P, const float *
     return (float)mn * c.hf_vscale;
 }
 
-// The body works on one tile of TILE environments starting at env0 and touches no other environment's state, so it serves two
-// callers: k_post_step (one workgroup per tile: the operator-level lg_post_physics_step) and the tail of the control-loop
-// kernel of lg_step, whose workgroups own the same environments (k_substeps, LG_RUN_POST).
+// The body works on one tile of TILE environments starting at env0 and touches no other environment's state.
 template <int TILE>
 __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, const int env0, int64_t counter, int inject, int init_done) {
     const lg_cfg &c = P->cfg;
@@ -1002,32 +990,23 @@ static int phys_pair_enabled() {
     return g_phys_pair;
 }
 template <int L, int J, bool LSTM>
-static void launch_substeps(int blocks, const DevParams *P, const float *a_in, int mode, int iters, int64_t counter, int inject, int init_done,
-                            hipStream_t s) {
-    if (phys_pair_enabled())
-        hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters, counter, inject, init_done);
-    else
-        hipLaunchKernelGGL((k_substeps<L, J, LSTM, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters, counter, inject, init_done);
+static void launch_substeps(int blocks, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {
+    if (phys_pair_enabled()) hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+    else hipLaunchKernelGGL((k_substeps<L, J, LSTM, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
 }
-// mode: LG_RUN_TORQUES | LG_RUN_PHYSICS | LG_RUN_POST; counter / inject / init_done are read by the post-step stage only
-extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, int64_t counter,
-                            int inject, int init_done, hipStream_t s) {
+extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s) {
     const int blocks = (N + 64 / L - 1) / (64 / L);
-    if (L == 4 && J == 3 && lstm) launch_substeps<4, 3, true>(blocks, P, a_in, mode, iters, counter, inject, init_done, s);
-    else if (L == 4 && J == 3) launch_substeps<4, 3, false>(blocks, P, a_in, mode, iters, counter, inject, init_done, s);
-    else if (L == 2 && J == 6 && !lstm) launch_substeps<2, 6, false>(blocks, P, a_in, mode, iters, counter, inject, init_done, s);
+    if (L == 4 && J == 3 && lstm) launch_substeps<4, 3, true>(blocks, P, a_in, mode, iters, s);
+    else if (L == 4 && J == 3) launch_substeps<4, 3, false>(blocks, P, a_in, mode, iters, s);
+    else if (L == 2 && J == 6 && !lstm) launch_substeps<2, 6, false>(blocks, P, a_in, mode, iters, s);
     else return -1;
     return 0;
-}
-// what follows the per-tile post-step: the trajectory generator's re-check of every env, then the single-workgroup epilogue
-extern "C" void lgk_post_tail(const DevParams *P, int N, int64_t counter, int inject, int traj, hipStream_t s) {
-    if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
 }
 extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, hipStream_t s) {
     constexpr int TILE = 16;
     hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done);
-    lgk_post_tail(P, N, counter, inject, traj, s);
+    if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
 }
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);

@@ -190,17 +190,14 @@ def test_rollout_properties_at_baseline_size():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("name,post_in_tail", [("anymal_c_flat", 0), ("anymal_c_pd_V", 0), ("anymal_c_rough", 0), ("cassie", 0), ("a1", 0),
-                                               ("anymal_b", 0), ("anymal_c_flat", 1), ("anymal_c_rough", 1), ("cassie", 1)])
-def test_fused_control_loop_equals_launch_per_substep(name, post_in_tail):
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_pd_V", "anymal_c_rough", "cassie", "a1", "anymal_b"])
+def test_fused_control_loop_equals_launch_per_substep(name):
     """lg_step's single-launch control loop (k_substeps: clip + decimation x {torque law, physics} with the state resident
     on chip) against the operator-level sequence lg_set_actions / decimation x {lg_compute_torques, lg_simulate} /
     lg_post_physics_step on a second context with the same seed (133 envs: the last block is ragged).  The operator-level
     entries run the same kernel with one stage switched off, so one instance of the torque code and of physics_lane serves
     both paths and fp32 state crossing HBM between launches is exact: every buffer must be EQUAL bit for bit, over 6 policy
-    steps with contacts, resets and the action clip, without re-gluing the two contexts.  post_in_tail = 1: lg_step also runs
-    post_physics_step inside the control-loop launch, each workgroup for its own environments (LG_FUSED_POST; Cassie: two
-    post-step tiles per workgroup, the last one ragged) -- same device code, so still EQUAL."""
+    steps with contacts, resets and the action clip, without re-gluing the two contexts."""
     z, meta = harness.load_fixture(name)
     n = 133
     cfg = harness.make_cfg(name)
@@ -216,7 +213,6 @@ def test_fused_control_loop_equals_launch_per_substep(name, post_in_tail):
         return harness.HipHandle(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), terrain=terrain, seed=7), hs)
     a, b = mk(), mk()
     try:
-        a.core.lib.lg_debug_set_fused_post(post_in_tail)
         rng = np.random.default_rng(9)
         A = meta["num_dofs"]
         for e in (a, b):
@@ -242,7 +238,6 @@ def test_fused_control_loop_equals_launch_per_substep(name, post_in_tail):
                         "lstm_h", "lstm_c", "episode_sums", "feet_air_time", "contact_forces", "commands", "last_dof_vel"):
                 np.testing.assert_array_equal(a.get(key), b.get(key), err_msg=f"step {t} {key}")
     finally:
-        a.core.lib.lg_debug_set_fused_post(0)
         a.close()
         b.close()
 
