@@ -33,6 +33,6 @@ print("== one PPO minibatch of the update (optimiser step .. next optimiser step
 print(timeline(lo, hi))
 print(f"   minibatch period: {(int(trace[hi]['Start_Timestamp']) - int(trace[lo]['Start_Timestamp'])) / 1e3:.1f} us")
 print("\n== one policy step of the rollout (k_substeps .. next k_substeps) ==")
-lo, hi = pick(si, ["k_post_step", "k_act_sample"])
+lo, hi = pick(si, ["k_post_step", "k_act_sample" if any("k_act_sample" in n for n in names) else "k_mlp_fwd"])
 print(timeline(lo, hi))
 print(f"   step period: {(int(trace[hi]['Start_Timestamp']) - int(trace[lo]['Start_Timestamp'])) / 1e3:.1f} us")
