@@ -113,10 +113,15 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
 // per CU that larger env counts use.
 #define LG_RUN_TORQUES 1
 #define LG_RUN_PHYSICS 2
-template <int L, int J, bool LSTM, bool PAIR>
-__global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
-    constexpr int A = L * J, EPW = 64 / L, ROWS = EPW * A, NR = ROWS * 8 / 256;
-    constexpr int PW = PAIR ? 2 : 1, LPE = PAIR ? 2 * L : L;    // physics waves of the block, physics lanes per env
+template <int L, int J, bool LSTM, bool PAIR, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
+    // NW waves per block.  NW = 4: two physics waves (pair-lane map) + two that only run the actuator net, 64/L envs.  NW = 2 (pair-lane
+    // map only): one physics wave + one actuator-net wave, 32/L envs -- two such blocks per CU, and no physics wave ever waits at a
+    // substep barrier for the other one's contacts (LG_SUBSTEPS_NW).
+    static_assert(NW == 4 || (NW == 2 && PAIR), "block shapes: 4 waves, or 2 waves with the pair-lane physics");
+    constexpr int NT = 64 * NW, RPP = NT / 8;                   // threads; actuator-net rows per pass (8 lanes per row)
+    constexpr int PW = PAIR ? NW / 2 : 1, LPE = PAIR ? 2 * L : L;    // physics waves of the block, physics lanes per env
+    constexpr int A = L * J, EPW = 64 * PW / LPE, ROWS = EPW * A, NR = ROWS * 8 / NT;
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -136,12 +141,12 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     __shared__ __attribute__((aligned(16))) float s_w[LSTM ? LG_LSTM_LDS : 4];
     __shared__ float s_act[ROWS], s_q[ROWS], s_qd[ROWS], s_tau[ROWS];
     __shared__ float s_cf[EPW * LG_MAX_BODIES * 3];          // net contact force per (env, body) of the last control substep
-    for (int t = tid; t < EPW * LG_MAX_BODIES * 3; t += 256) s_cf[t] = 0.f;
-    for (int t = tid; t < L * LG_LT_STRIDE; t += 256) s_lt[t] = (&P->leg_tab[0][0])[t];
+    for (int t = tid; t < EPW * LG_MAX_BODIES * 3; t += NT) s_cf[t] = 0.f;
+    for (int t = tid; t < L * LG_LT_STRIDE; t += NT) s_lt[t] = (&P->leg_tab[0][0])[t];
     if (LSTM)
-        for (int t = tid; t < LG_LSTM_LDS; t += 256) s_w[t] = P->lstm_img[t];
+        for (int t = tid; t < LG_LSTM_LDS; t += NT) s_w[t] = P->lstm_img[t];
     const size_t row0 = (size_t)env0 * A;
-    for (int t = tid; t < ROWS; t += 256) {
+    for (int t = tid; t < ROWS; t += NT) {
         const bool in = t < nrow;
         const size_t r = row0 + (in ? t : 0);
         const float a = fminf(fmaxf(a_in[r], -c.clip_actions), c.clip_actions);      // LR:86-87 (idempotent on clipped input)
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     if (LSTM && do_tau) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int rl = r * 32 + (tid >> 3);
+            const int rl = r * RPP + (tid >> 3);
             const size_t idx = (row0 + (rl < nrow ? rl : 0)) * 8 + (tid & 7);
             h0[r] = P->buf.lstm_h[idx]; c0[r] = P->buf.lstm_c[idx]; h1[r] = P->buf.lstm_h[ls + idx]; c1[r] = P->buf.lstm_c[ls + idx];
         }
@@ -197,14 +202,14 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
                 float x0[NR], x1[NR], y[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const int rl = r * 32 + (tid >> 3);
+                    const int rl = r * RPP + (tid >> 3);
                     x0[r] = (s_act[rl] * c.action_scale + c.default_dof_pos[rl % A] - s_q[rl]) * s_w[0];
                     x1[r] = s_qd[rl] * s_w[1];
                 }
                 lstm8_rows<NR>(s_w + 4 + (tid & 7) * LG_LSTM_REC, tid & 7, x0, x1, h0, c0, h1, c1, y);
                 if ((tid & 7) == 0) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) s_tau[r * 32 + (tid >> 3)] = s_w[2] * (y[r] + s_w[3]);
+                    for (int r = 0; r < NR; ++r) s_tau[r * RPP + (tid >> 3)] = s_w[2] * (y[r] + s_w[3]);
                 }
                 __syncthreads();
                 if (phys) {
@@ -267,15 +272,15 @@ __global__ void __launch_bounds__(256, 1) k_substeps(const DevParams *__restrict
     }
     // ---- write back (once per launch)
     if (do_phys)
-        for (int t = tid; t < min(EPW, N - env0) * B * 3; t += 256) P->buf.contact_forces[(size_t)env0 * B * 3 + t] = s_cf[t];
-    for (int t = tid; t < nrow; t += 256) {
+        for (int t = tid; t < min(EPW, N - env0) * B * 3; t += NT) P->buf.contact_forces[(size_t)env0 * B * 3 + t] = s_cf[t];
+    for (int t = tid; t < nrow; t += NT) {
         if (do_phys) reinterpret_cast<float2 *>(P->buf.dof_state)[row0 + t] = make_float2(s_q[t], s_qd[t]);
         if (do_tau) P->buf.torques[row0 + t] = s_tau[t];
     }
     if (LSTM && do_tau) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int rl = r * 32 + (tid >> 3);
+            const int rl = r * RPP + (tid >> 3);
             if (rl < nrow) {
                 const size_t idx = (row0 + rl) * 8 + (tid & 7);
                 P->buf.lstm_h[idx] = h0[r]; P->buf.lstm_c[idx] = c0[r]; P->buf.lstm_h[ls + idx] = h1[r]; P->buf.lstm_c[ls + idx] = c1[r];
@@ -989,16 +994,27 @@ static int phys_pair_enabled() {
     if (g_phys_pair < 0) { const char *e = getenv("LG_PHYS_PAIR"); g_phys_pair = e ? (atoi(e) ? 1 : 0) : 1; }
     return g_phys_pair;
 }
+// LG_SUBSTEPS_NW (pair-lane physics only): 4 = blocks of 4 waves and 64/L envs, 2 = blocks of 2 waves and 32/L envs; 0 / unset = by
+// topology.  Measured per lg_step: quadruped 117.2 (4) vs 122.4 us (2: two blocks share a CU and its LDS / instruction cache for
+// nothing, the chain per wave is the same); biped 148.7 (4: 128 blocks, half the CUs idle) vs 145.5 us (2: 256 blocks).  Results are
+// bit-identical either way (tests/test_hip_env.py::test_control_loop_block_shapes_are_bit_identical).
+static int g_substeps_nw = -1;
+extern "C" void lgk_debug_set_substeps_nw(int v) { g_substeps_nw = v == 2 ? 2 : v == 4 ? 4 : 0; }
 template <int L, int J, bool LSTM>
-static void launch_substeps(int blocks, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {
-    if (phys_pair_enabled()) hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
-    else hipLaunchKernelGGL((k_substeps<L, J, LSTM, false>), dim3(blocks), dim3(256), 0, s, P, a_in, mode, iters);
+static void launch_substeps(int N, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {
+    if (g_substeps_nw < 0) { const char *e = getenv("LG_SUBSTEPS_NW"); g_substeps_nw = e ? (atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0) : 0; }
+    const int epw4 = 64 / L, epw2 = 32 / L;
+    const int nw = g_substeps_nw ? g_substeps_nw : (L == 2 ? 2 : 4);
+    if (phys_pair_enabled() && nw == 2)
+        hipLaunchKernelGGL((k_substeps<L, J, LSTM, true, 2>), dim3((N + epw2 - 1) / epw2), dim3(128), 0, s, P, a_in, mode, iters);
+    else if (phys_pair_enabled())
+        hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3((N + epw4 - 1) / epw4), dim3(256), 0, s, P, a_in, mode, iters);
+    else hipLaunchKernelGGL((k_substeps<L, J, LSTM, false>), dim3((N + epw4 - 1) / epw4), dim3(256), 0, s, P, a_in, mode, iters);
 }
 extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s) {
-    const int blocks = (N + 64 / L - 1) / (64 / L);
-    if (L == 4 && J == 3 && lstm) launch_substeps<4, 3, true>(blocks, P, a_in, mode, iters, s);
-    else if (L == 4 && J == 3) launch_substeps<4, 3, false>(blocks, P, a_in, mode, iters, s);
-    else if (L == 2 && J == 6 && !lstm) launch_substeps<2, 6, false>(blocks, P, a_in, mode, iters, s);
+    if (L == 4 && J == 3 && lstm) launch_substeps<4, 3, true>(N, P, a_in, mode, iters, s);
+    else if (L == 4 && J == 3) launch_substeps<4, 3, false>(N, P, a_in, mode, iters, s);
+    else if (L == 2 && J == 6 && !lstm) launch_substeps<2, 6, false>(N, P, a_in, mode, iters, s);
     else return -1;
     return 0;
 }

@@ -243,6 +243,48 @@ def test_fused_control_loop_equals_launch_per_substep(name):
 
 
 @pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
+def test_control_loop_block_shapes_are_bit_identical(name):
+    """The control loop on blocks of 4 waves (two physics waves, 64/L envs) against blocks of 2 waves (one physics wave, 32/L envs:
+    LG_SUBSTEPS_NW=2): which workgroup an environment lands in and how many waves share its barriers must not change a bit of
+    its state -- 133 envs (ragged last block in both shapes), 6 policy steps with contacts and resets."""
+    z, meta = harness.load_fixture(name)
+    n = 133
+    cfg = harness.make_cfg(name)
+    cfg.env.num_envs = n
+    meta = dict(meta, num_envs=n)
+    from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float
+    from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
+    cm = compile_model(resolve_model("", meta["robot"]))
+    terrain = harness.FixtureTerrain(z, meta, cfg) if "const_height_samples" in z.files else None
+    hs = z["const_height_samples"] if terrain else None
+
+    def mk():
+        return harness.HipHandle(EnvSetup(cfg, cm, sim_dt_float(cfg.sim.dt), terrain=terrain, seed=7), hs)
+    a, b = mk(), mk()
+    lib = a.core.lib
+    try:
+        rng = np.random.default_rng(11)
+        A = meta["num_dofs"]
+        for e in (a, b):
+            e.set_step_counter(0)
+            e.inject(0)
+            e.call("reset_all")
+        for t in range(6):
+            act = rng.uniform(-3, 3, (n, A)).astype(np.float32)
+            lib.lg_debug_set_substeps_nw(4)
+            a.step(act)
+            lib.lg_debug_set_substeps_nw(2)
+            b.step(act)
+            for key in ("reset", "episode_length", "torques", "dof_state", "root_states", "obs", "rew", "lstm_h", "lstm_c",
+                        "contact_forces", "feet_air_time"):
+                np.testing.assert_array_equal(a.get(key), b.get(key), err_msg=f"step {t} {key}")
+    finally:
+        lib.lg_debug_set_substeps_nw(0)                            # back to the default: by topology
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
 def test_pair_lane_physics_equals_one_lane_per_leg(name):
     """The two lane maps of the physics -- two lanes per (env, leg) splitting every spatial quantity by rows (lg_physics_pair.h,
     the default) and one lane per (env, leg) (lg_physics.h) -- are the same algorithm with differently associated fp32 sums.
