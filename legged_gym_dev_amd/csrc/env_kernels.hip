@@ -634,7 +634,26 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     STAMP(0);
 
     // ---- phase H: height scan of the pre-reset pose (LR:356-357)
+    // What every scan point of an env shares -- the normalised yaw quaternion and the base position -- is computed once per env
+    // into LDS and the table of scan points is staged there too: a point then costs its three height-sample gathers and nothing
+    // else from memory (height_sample re-reads the root state and its table entry and repeats the sqrt / two divisions per point;
+    // same arithmetic on the same values, so the heights are bit-identical).  The heights stay in LDS for phase O.
+    constexpr int HP_LDS = 192;                                   // scan points staged (ANYmal 17 x 11 = 187, Cassie 121)
+    __shared__ float s_hp[2 * HP_LDS];
+    __shared__ float s_hr[TILE][4];
+    __shared__ float s_mh[TILE * HP_LDS];
+    const bool hstage = c.measure_heights && c.terrain_type == 1 && H <= HP_LDS;
     if (c.measure_heights) {
+        if (hstage) {
+            for (int t = tid; t < 2 * H; t += LG_TILE_THREADS) s_hp[t] = P->height_points[t];
+            if (tid < nE) {
+                const float *r = P->buf.root_states + (size_t)(env0 + tid) * 13;
+                const float qz = r[5], qw = r[6];
+                const float n = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+                s_hr[tid][0] = qz / n; s_hr[tid][1] = qw / n; s_hr[tid][2] = r[0]; s_hr[tid][3] = r[1];
+            }
+            __syncthreads();
+        }
         // HU scan points per lane and trip: their 3 HU height-sample gathers are independent and in flight together (one lane
         // per point and trip exposed three dependent-latency round trips per trip to a lone wave)
         constexpr int HU = 4;                                     // scan points per lane and trip (8: slower, 25.7 k vs 21.3 k cycles at 187 points)
@@ -643,13 +662,31 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
                 const int idx = min(idx0 + u * LG_TILE_THREADS, nE * H - 1);
-                const int e = env0 + idx / H, h = idx % H;
-                v[u] = c.terrain_type == 1 ? height_sample(P, P->buf.root_states + (size_t)e * 13, h) : 0.0f;
+                const int el = idx / H, h = idx % H;
+                if (hstage) {                                     // LR:877-915, the body of height_sample on the staged values
+                    const float qy[4] = {0.0f, 0.0f, s_hr[el][0], s_hr[el][1]};
+                    const V3 w = quat_apply(qy, V3{s_hp[2 * h], s_hp[2 * h + 1], 0.0f});
+                    const float x = (w.x + s_hr[el][2] + c.border_size) / c.hf_hscale;
+                    const float y = (w.y + s_hr[el][3] + c.border_size) / c.hf_hscale;
+                    int px = (int)x, py = (int)y;
+                    px = min(max(px, 0), c.hf_rows - 2);
+                    py = min(max(py, 0), c.hf_cols - 2);
+                    const int16_t *hs = P->height_samples + (size_t)px * c.hf_cols + py;
+                    const int16_t h1 = hs[0], h2 = hs[c.hf_cols], h3 = hs[1];
+                    int16_t mn = h1 < h2 ? h1 : h2;
+                    mn = mn < h3 ? mn : h3;
+                    v[u] = (float)mn * c.hf_vscale;
+                } else {
+                    v[u] = c.terrain_type == 1 ? height_sample(P, P->buf.root_states + (size_t)(env0 + el) * 13, h) : 0.0f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
                 const int idx = idx0 + u * LG_TILE_THREADS;
-                if (idx < nE * H) P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H] = v[u];
+                if (idx < nE * H) {
+                    P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H] = v[u];
+                    if (hstage) s_mh[(idx / H) * HP_LDS + idx % H] = v[u];
+                }
             }
         }
     }
@@ -820,7 +857,10 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     // block by block: a quarter of the evaluations of one per entry (rough terrain: 235 entries x 16 envs per workgroup).
     constexpr int OBS_LDS = 256;                                        // widest observation row staged (rough terrain: 235)
     __shared__ float s_ob[TILE * OBS_LDS];
+    __shared__ float s_nv[OBS_LDS];                                     // the noise scale vector: one global round trip for all trips
     const bool stage = c.add_noise && O <= OBS_LDS;
+    if (stage)
+        for (int k = tid; k < O; k += LG_TILE_THREADS) s_nv[k] = P->noise_vec[k];   // (the barrier before the noise pass orders it)
     auto emit = [&](int i, int k, float v) {
         if (stage) { s_ob[(i - env0) * OBS_LDS + k] = v; return; }
         if (c.add_noise) v += (2.0f * uni(P, i, s_noise + k, counter, inject) - 1.0f) * P->noise_vec[k];
@@ -848,13 +888,14 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
         emit(i, ob + A + j, st.y * c.obs_scale_dof_vel);
         emit(i, ob + 2 * A + j, act);
     }
+    STAMP(5);
     if (c.measure_heights)
         for (int idx0 = tid; idx0 < nE * H; idx0 += 4 * LG_TILE_THREADS) { // height entries, four in flight
             float hv[4], rz[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = min(idx0 + u * LG_TILE_THREADS, nE * H - 1);
-                hv[u] = P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H];
+                hv[u] = hstage ? s_mh[(idx / H) * HP_LDS + idx % H] : P->buf.measured_heights[(size_t)(env0 + idx / H) * H + idx % H];
                 rz[u] = P->buf.root_states[(size_t)(env0 + idx / H) * 13 + 2];
             }
 #pragma unroll
@@ -863,11 +904,12 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
                 if (idx < nE * H) emit(env0 + idx / H, ob + 3 * A + idx % H, clampf(rz[u] - 0.5f - hv[u], -1.0f, 1.0f) * c.obs_scale_height);
             }
         }
+    STAMP(6);
     if (stage) {
         __syncthreads();
         const int b0 = s_noise >> 2, nb = ((s_noise + O + 3) >> 2) - b0;  // Philox blocks that hold the noise slots
-        for (int idx = tid; idx < nE * nb; idx += LG_TILE_THREADS) {
-            const int e = idx / nb, b = b0 + idx % nb, i = env0 + e;
+        for (int idx = tid; idx < nE * nb; idx += LG_TILE_THREADS) {   // (two blocks per lane and trip: no faster -- the Philox rounds
+            const int e = idx / nb, b = b0 + idx % nb, i = env0 + e;   //  are quarter-rate multiplies, throughput-bound on the SIMD)
             float u4[4] = {0.f, 0.f, 0.f, 0.f};
             if (!inject) philox_uniform4(c.seed, (uint32_t)(c.env_offset + i), (uint64_t)counter, (uint32_t)b, u4);
 #pragma unroll
@@ -876,11 +918,12 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
                 if (k < 0 || k >= O) continue;
                 const float u = inject ? P->buf.inject_uniforms[(size_t)i * P->K + 4 * b + r] : u4[r];
                 float v = s_ob[e * OBS_LDS + k];
-                v += (2.0f * u - 1.0f) * P->noise_vec[k];
+                v += (2.0f * u - 1.0f) * s_nv[k];
                 P->buf.obs[(size_t)i * O + k] = clampf(v, -c.clip_obs, c.clip_obs);
             }
         }
     }
+    STAMP(7);
     for (int idx = tid; idx < nE * A; idx += LG_TILE_THREADS) {
         const size_t ij = (size_t)env0 * A + idx;
         P->buf.last_actions[ij] = P->buf.actions[ij];
