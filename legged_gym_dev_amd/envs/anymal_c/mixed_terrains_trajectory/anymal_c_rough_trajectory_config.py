@@ -5,7 +5,11 @@ from legged_gym_dev_amd.envs.base.legged_robot_trajectory_config import LeggedRo
 from legged_gym_dev_amd.envs.anymal_c.mixed_terrains.anymal_c_rough_config import AnymalCRoughCfg
 
 AnymalCRoughTrajectoryCfg = cfg_class("AnymalCRoughTrajectoryCfg", LeggedRobotTrajectoryCfg, dict(
-    env=S(num_envs=4096, num_actions=12),
+    # num_observations: the fork's base class says 240 (legged_robot_trajectory_config.py:38, "Changes with RoM"), which is the width for a
+    # 4-point trajectory window; with the committed generator (N = 10, :94) and the height scan of this terrain the observation
+    # LeggedRobotTrajectory.compute_observations builds (:280-295) is 9 + 2*10 + 3*12 + 187 = 252 wide, and the reference's policy
+    # construction fails on the mismatch.  Repaired here like the other fork defects.
+    env=S(num_envs=4096, num_actions=12, num_observations=252),
     terrain=S(mesh_type='trimesh'),
     init_state=S(pos=[0.0, 0.0, 0.6], default_joint_angles=dict(AnymalCRoughCfg.init_state.default_joint_angles)),
     control=S(stiffness={'HAA': 80.0, 'HFE': 80.0, 'KFE': 80.0}, damping={'HAA': 2.0, 'HFE': 2.0, 'KFE': 2.0}, action_scale=0.5,

@@ -142,7 +142,8 @@ def test_trajectory_dataset_rollout():
 
 
 @pytest.mark.parametrize("case", [("anymal_c_flat", 1000, [512, 256, 128]), ("cassie", 777, [512, 256, 128]), ("anymal_c_flat", 7, [64, 32]),
-                                  ("anymal_c_flat_trajectory", 1234, [512, 256, 128])])
+                                  ("anymal_c_flat_trajectory", 1234, [512, 256, 128]), ("anymal_c_rough_trajectory", 600, [512, 256, 128]),
+                                  ("anymal_c_rough", 2049, [96, 40, 24])])
 def test_sizes_off_every_tile_grid(case):
     """Env counts that are a multiple of no tile (control loop: 16 / 32 envs per workgroup; post-step: 16; one-launch act: 32
     rows; minibatch rows off the 128-row GEMM and 64-row head grids; fewer envs than action dimensions) through the product
