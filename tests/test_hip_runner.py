@@ -78,12 +78,13 @@ def test_learn_save_resume_export_play(tmp_path, monkeypatch):
     env2.close(); runner2.ppo.close()
 
 
-def test_play_script_runs(tmp_path, monkeypatch):
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough"])
+def test_play_script_runs(task, tmp_path, monkeypatch):
     import legged_gym_dev_amd
     from legged_gym_dev_amd.envs import task_registry
     monkeypatch.setattr(legged_gym_dev_amd, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
     monkeypatch.setattr(sys.modules["legged_gym_dev_amd.utils.task_registry"], "LEGGED_GYM_ROOT_DIR", str(tmp_path))
-    args = _args("anymal_c_flat", 16)
+    args = _args(task, 16)
     env, _ = task_registry.make_env(name=args.task, args=args)
     _, shared = task_registry.get_cfgs(args.task)       # registered cfg objects are shared and mutated in place (as in the reference)
     shared.runner.resume = False
@@ -97,7 +98,7 @@ def test_play_script_runs(tmp_path, monkeypatch):
     play = importlib.import_module("play")
     monkeypatch.setattr(play, "LEGGED_GYM_ROOT_DIR", str(tmp_path))
     monkeypatch.chdir(tmp_path)
-    rec = play.play(_args("anymal_c_flat", 1), num_steps=120, out_mat=str(tmp_path / "play_data.mat"))
+    rec = play.play(_args(task, 1), num_steps=120, out_mat=str(tmp_path / "play_data.mat"))
     assert rec["pos"].shape == (120, 3) and np.isfinite(rec["torque"]).all() and np.abs(rec["action"]).sum() > 0
     import scipy.io
     m = scipy.io.loadmat(str(tmp_path / "play_data.mat"))
