@@ -192,6 +192,59 @@ def test_returns_and_gradients_match_torch(O):
     hip.close()
 
 
+def test_privileged_critic_observations():
+    """Asymmetric actor / critic inputs (rsl_rl's num_privileged_obs: the critic sees its own observation vector): 65-wide actor
+    and 169-wide critic observations -- neither a multiple of 8, so both minibatch gathers and both first layers carry pad
+    columns of different widths.  act() (one launch), the stored critic observations, returns, and the gradients of one
+    minibatch against autograd."""
+    from legged_gym_dev_amd.rl.ppo import HipPPO
+    from oracle import ppo_torch as pt
+    N, O, OC, A, T = 256, 65, 169, 12, 4
+    torch.manual_seed(3)
+    hip = HipPPO(N, O, OC, A, POLICY, ALG, T, device="cuda:0", seed=3)
+    ac = pt.ActorCritic(O, OC, A, POLICY["actor_hidden_dims"], POLICY["critic_hidden_dims"], POLICY.get("activation", "elu"),
+                        POLICY["init_noise_std"]).cuda()
+    ac.load_state_dict({k: v.clone() for k, v in hip.state_dict().items()})
+    g = torch.Generator(device="cuda").manual_seed(6)
+    hip.inject_noise(1)
+    for t in range(T):
+        obs = torch.randn(N, O, device="cuda", generator=g)
+        cobs = torch.randn(N, OC, device="cuda", generator=g)
+        noise = torch.randn(N, A, device="cuda", generator=g)
+        hip.t["noise"].copy_(noise)
+        act = hip.act(obs, cobs).clone()
+        with torch.no_grad():
+            mu, v = ac.actor(obs), ac.critic(cobs).squeeze(-1)
+        torch.testing.assert_close(hip.t["act_mu"], mu, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(hip.t["act_values"], v, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(act, mu + ac.std * noise, rtol=2e-5, atol=2e-5)
+        assert torch.equal(hip.t["critic_obs"][t], cobs) and torch.equal(hip.t["obs"][t], obs)
+        rew = torch.randn(N, device="cuda", generator=g)
+        dones = (torch.rand(N, device="cuda", generator=g) < 0.1).to(torch.uint8)
+        hip.process_env_step(rew, dones, {"time_outs": torch.zeros(N, dtype=torch.uint8, device="cuda")})
+    hip.compute_returns(torch.randn(N, OC, device="cuda", generator=g))
+    hip._call("begin_update")
+    torch.cuda.synchronize()
+    perm = hip.t["perm"].long()
+    R = T * N // ALG["num_mini_batches"]
+    algo = pt.PPO(ac, clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-3, max_grad_norm=1.0,
+                  use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01)
+    flat = lambda name: hip.t[name].reshape(T * N, *hip.t[name].shape[2:])
+    idx = perm[:R]
+    hip._call("minibatch_backward", 0, 0)
+    batch = (flat("obs")[idx], flat("critic_obs")[idx], flat("actions")[idx], flat("values")[idx].unsqueeze(-1),
+             flat("advantages")[idx].unsqueeze(-1), flat("returns")[idx].unsqueeze(-1), flat("log_prob")[idx].unsqueeze(-1),
+             flat("mu")[idx], hip.t["sigma"].clone().expand(R, A))
+    ac.zero_grad()
+    loss, kl, vl, sl = algo.minibatch_loss(*(b.clone() for b in batch))
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in ac.parameters()])
+    got = hip.t["grads"][: hip.num_params]
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max()))
+    assert float((got - ref).norm() / ref.norm()) < 2e-4
+    hip.close()
+
+
 def test_full_update_tracks_torch():
     """5 epochs x 4 minibatches on the same permutation: parameters stay within 2e-3 of torch's."""
     N, O, A, T = 256, 48, 12, 8
