@@ -334,7 +334,7 @@ def main():
     env, runner = make_runner(args.num_envs, hidden, device, rank, world)
     el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world
-    out = {"metric": "env-steps/sec (whole node), ANYmal-C flat 4096 envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
+    out = {"metric": f"env-steps/sec (whole node), ANYmal-C flat {args.num_envs} envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
