@@ -259,12 +259,37 @@ def cpu_baseline(num_envs, hidden):
                       f"+ {E * MB} minibatch updates of {R} rows ({t_upd:.2f}s); {cores} threads"}
 
 
-def rank_environments(n, port, base=None):
+def rank_environments(n, port, base=None, comm_port=None):
     """Environment of each of the n child ranks (what torch.distributed.run would export)."""
     base = dict(os.environ if base is None else base)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    if comm_port is not None:
+        base["LG_COMM_PORT"] = str(comm_port)                   # NativeComm's id exchange (rl/comm.py): a port probed free as well
     return [dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)) for r in range(n)]
+
+
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT a HIP / torch.cuda call (torch.cuda.device_count() can initialise the HIP runtime
+    in the launcher parent, whose children must start from a GPU-clean process): KFD topology nodes with SIMDs, narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None if the topology is not readable (then a child rank fails instead)."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for p in nodes:
+        try:
+            with open(p) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except OSError:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def launch_ranks(n, argv):
@@ -272,14 +297,16 @@ def launch_ranks(n, argv):
     Returns the exit code: 0 only if every rank ended cleanly; the others are stopped when one fails."""
     import socket
     import subprocess
-    if os.environ.get("LG_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < n:
-        print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} visible", file=sys.stderr)
+    have = visible_gpu_count()
+    if os.environ.get("LG_BENCH_SHARE_GPU") != "1" and have is not None and have < n:
+        print(f"bench.py: --gpus {n} but {have} visible", file=sys.stderr)
         return 2
-    with socket.socket() as s:
+    with socket.socket() as s, socket.socket() as s2:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+        s2.bind(("127.0.0.1", 0))
+        port, comm_port = s.getsockname()[1], s2.getsockname()[1]
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e)
-             for e in rank_environments(n, port)]
+             for e in rank_environments(n, port, comm_port=comm_port)]
     rc = 0
     pending = list(procs)
     while pending:
@@ -345,7 +372,7 @@ def main():
                       "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
     # what the number was measured on: how often the random-init policy makes robots fall, and whether the
     # physics fault guard ever fired (it must not)
-    ep_done = int(runner.ppo.t["ep_ring_count"].cpu())
+    ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
     steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2)
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
     out["config"]["physics_fault_resets"] = int(env.fault_total.cpu())

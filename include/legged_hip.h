@@ -318,6 +318,9 @@ int lg_ppo_begin_update(lg_ppo *p);                /* new permutation, zero loss
 int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb);   /* fwd, loss, bwd -> grads (+KL tail) */
 int lg_ppo_minibatch_step(lg_ppo *p);              /* KL-adaptive lr, clip_grad_norm, Adam; clears grads */
 int lg_ppo_end_update(lg_ppo *p);                  /* finalise mean losses, clear storage */
+/* The caller wrote lg_ppo_buffers.params itself (checkpoint load, a broadcast of its own): the weight images the rollout forward
+ * reads are re-derived by the next lg_ppo_act.  (lg_ppo_minibatch_step and lg_ppo_broadcast_params mark them stale themselves.) */
+int lg_ppo_params_changed(lg_ppo *p);
 /* actor mean only (act_inference) for play/eval */
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows);
 

@@ -67,6 +67,10 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
         g_err = "no physics kernel instantiated for this topology (have 4x3 and 2x6)";
         return -4;
     }
+    if (cfg->use_actuator_net && !(L == 4 && J == 3)) {
+        g_err = "the actuator-net control loop is instantiated for the 4x3 topology only (have 4x3 PD, 4x3 actuator net, 2x6 PD)";
+        return -4;
+    }
     const int ncmd = cfg->traj.enabled ? 2 * cfg->traj.N : 3;
     if (O != 9 + ncmd + 3 * A + (cfg->measure_heights ? H : 0)) { g_err = "num_obs inconsistent with the observation layout"; return -5; }
     if (cfg->traj.enabled && (cfg->traj.N < 1 || cfg->traj.dN != 1 || cfg->traj.N * cfg->traj.dN + 1 > LG_TRAJ_MAX_PTS)) {

@@ -945,7 +945,8 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *
 
 // Single-workgroup epilogue: extras["episode"], extras["time_outs"] (only refreshed when >=1 env
 // reset this step: the early return of LR:156-157 keeps the previous, stale values), terrain level mean.
-__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P, int64_t counter, int inject) {
+// accumulate = 0 (lg_reset_ids: a reset made outside step()): the per-step logging sums and their step count stay untouched.
+__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P, int64_t counter, int inject, int accumulate) {
     const lg_cfg &c = P->cfg;
     const int N = c.num_envs, tid = threadIdx.x;
     const int n = *P->reset_count;
@@ -978,10 +979,12 @@ __global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ 
         for (int i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(P->reset_mark)[i] = make_uint4(0u, 0u, 0u, 0u);
         for (int i = (n16 << 4) + tid; i < N; i += 256) P->reset_mark[i] = 0;
     }
-    if (tid < LG_NUM_TERMS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
+    if (accumulate && tid < LG_NUM_TERMS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
     if (tid == 0) {
-        P->buf.extras_episode_acc[LG_NUM_TERMS] += P->buf.extras_terrain_level[0];
-        P->buf.extras_episode_acc[LG_NUM_TERMS + 1] += 1.0f;
+        if (accumulate) {
+            P->buf.extras_episode_acc[LG_NUM_TERMS] += P->buf.extras_terrain_level[0];
+            P->buf.extras_episode_acc[LG_NUM_TERMS + 1] += 1.0f;
+        }
         P->buf.n_reset[0] = n; *P->reset_count = 0;
         const int nf = *P->fault_count;
         P->buf.n_fault[0] = nf; P->buf.fault_total[0] += nf; *P->fault_count = 0;
@@ -1065,7 +1068,7 @@ extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int in
     constexpr int TILE = 16;
     hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done);
     if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject, 1);
 }
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);
@@ -1074,5 +1077,5 @@ extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int
                               hipStream_t s) {
     hipLaunchKernelGGL(k_reset_ids, dim3(n < 1024 ? n : 1024), dim3(LG_TILE_THREADS), 0, s, P, ids, n, counter, inject, init_done);
     if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject, 0);
 }

@@ -67,6 +67,8 @@ struct lg_ppo {
     int overlap;
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;
+    int params_dirty;                        // the fp32 parameters changed since the rollout images (fragment-order weights / bf16 planes)
+                                             // were derived from them: optimiser step, broadcast, lg_ppo_params_changed()
     int fused_act;                           // rollout forward through k_mlp_fwd when the network shape allows (else per-layer GEMMs)
     MlpArgs mlp;                             // its arguments (fragment-order weight image allocated at create)
                          // gradients hold a backward pass that no optimiser step has consumed (and zeroed)
@@ -135,9 +137,7 @@ static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int ma
 // as soon as the layer's weight-gradient GEMM is done.  b_l was summed by the input-gradient GEMM of layer l+1 (or by the loss
 // kernel for the head), which the weight-gradient GEMM of layer l already waited for.  The head's bucket also carries std and
 // the [KL sum | pad] tail.  The collectives of one bucket are one RCCL group.
-static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
-    float *bufs[4];
-    int64_t counts[4];
+static int bucket_extents(lg_ppo *p, int l, float **bufs, int64_t *counts) {
     int n = 0;
     for (int z = 0; z < 2; ++z) {
         Net &net = p->net[z];
@@ -148,6 +148,12 @@ static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
         bufs[n] = p->dev.grads + p->dev.off_std; counts[n++] = p->cfg.num_actions;
         bufs[n] = p->dev.grads + p->dev.num_params; counts[n++] = 2;
     }
+    return n;
+}
+static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
+    float *bufs[4];
+    int64_t counts[4];
+    const int n = bucket_extents(p, l, bufs, counts);
     hipStream_t cs = lg_comm_stream_(p->comm);
     (void)hipEventRecord(p->ev_bucket, ready_on);
     (void)hipStreamWaitEvent(cs, p->ev_bucket, 0);
@@ -262,7 +268,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         hipEventCreateWithFlags(&p->ev_bucket, hipEventDisableTiming) != hipSuccess) {
         lg_set_error("stream/event creation failed"); delete p; return -100;
     }
-    p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0;
+    p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0; p->params_dirty = 1;
     p->comm = nullptr; p->comm_rc = 0;
     if (getenv("LG_XCD_REMAP")) ppok_debug_set_xcd_remap(atoi(getenv("LG_XCD_REMAP")));
     if (getenv("LG_DW_T")) ppok_debug_set_dw_t(atoi(getenv("LG_DW_T")));
@@ -419,13 +425,15 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
     if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
     const float *cobs = critic_obs ? critic_obs : obs;
     int fused = -1;
+    const bool dirty = p->params_dirty != 0;
+    p->params_dirty = 0;
     if (p->fused_act) {
-        // the image is built from the fp32 parameters by the first act of a rollout (the optimiser, a checkpoint load or the
-        // initial broadcast may have written them since the last one)
+        // the image is rebuilt from the fp32 parameters whenever they changed since it was built (optimiser step, broadcast, or a
+        // host write announced through lg_ppo_params_changed: checkpoint load, load_state_dict) -- also in the middle of a rollout
         MlpArgs &g = p->mlp;
         g.in[0] = obs; g.in[1] = cobs;
         g.out[0] = p->net[0].act[p->net[0].nl]; g.out[1] = p->net[1].act[p->net[1].nl];
-        if (p->step == 0) ppok_mlp_frag_build(&g, p->stream);
+        if (dirty) ppok_mlp_frag_build(&g, p->stream);
         static const int fuse_sample = getenv("LG_FUSED_SAMPLE") ? atoi(getenv("LG_FUSED_SAMPLE")) : 1;
         g.sample = fuse_sample; g.t = p->step; g.inject = p->inject; g.act_count = p->act_count;
         fused = ppok_mlp_fwd(&g, &p->dev, 3, p->stream);
@@ -434,7 +442,7 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
     if (fused != 0) {
         // per-layer GEMMs on the optimiser's weight planes (no re-split of W per tile); same freshness rule as above
         static const int act_planes = getenv("LG_ACT_PLANES") ? atoi(getenv("LG_ACT_PLANES")) : 1;
-        if (act_planes && p->step == 0) ppok_sync_planes(&p->dev, p->stream);
+        if (act_planes && (dirty || p->step == 0)) ppok_sync_planes(&p->dev, p->stream);
         forward(p, p->cfg.num_envs, obs, cobs, 3, 0, act_planes != 0);
     }
     ppok_act_sample(&p->dev, obs, cobs, p->net[0].act[p->net[0].nl], p->net[1].act[p->net[1].nl], p->step, p->act_count,
@@ -526,6 +534,7 @@ int lg_ppo_minibatch_step(lg_ppo *p) {
     if (ppok_step(&p->dev, (int)(p->update_count & 1), &other, next, p->stream)) p->mb_ready = next;
     p->mb_last = -1;
     p->grads_dirty = 0;
+    p->params_dirty = 1;
     p->update_count++;
     return launch_ok();
 }
@@ -535,7 +544,19 @@ int lg_ppo_end_update(lg_ppo *p) { p->step = 0; return 0; }
 int lg_ppo_set_comm(lg_ppo *p, lg_comm *c) { p->comm = c; return 0; }
 int lg_ppo_allreduce_adv_moments(lg_ppo *p, lg_comm *c) { return lg_comm_allreduce_sum(c, p->dev.adv_partial, 4, p->stream); }
 int lg_ppo_broadcast_params(lg_ppo *p, lg_comm *c, int root) {
+    p->params_dirty = 1;
     return lg_comm_broadcast(c, p->dev.params, p->dev.num_params + 2, root, p->stream);
+}
+int lg_ppo_params_changed(lg_ppo *p) { p->params_dirty = 1; return 0; }
+
+// The extents reduce_layer_bucket() hands to RCCL for layer l, as offsets into the flat gradient buffer (host-side, for tests:
+// the buckets of all layers must tile [0, num_reduce) exactly once).  Returns the number of extents (<= 4).
+int lg_ppo_debug_bucket_extents(lg_ppo *p, int l, int64_t *offsets, int64_t *counts) {
+    if (l < 0 || l >= p->net[0].nl) return -1;
+    float *bufs[4];
+    const int n = bucket_extents(p, l, bufs, counts);
+    for (int k = 0; k < n; ++k) offsets[k] = bufs[k] - p->dev.grads;
+    return n;
 }
 
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows) {

@@ -42,8 +42,9 @@ def draw_env_constants(cfg, num_envs_total, body0_mass, terrain):
     out["env_origins"] = origins
     friction = torch.ones(N)
     dmass = np.zeros(N, dtype=np.float64)
+    start = origins.clone()                                # actor start position: env origin + U(-1, 1) in xy (:739-741)
     for i in range(N):
-        torch.rand(2, 1)                                   # start-pose jitter (overwritten by the first reset)
+        start[i, :2] += (1.0 - (-1.0)) * torch.rand(2, 1).squeeze(1) + (-1.0)
         if cfg.domain_rand.randomize_friction and i == 0:
             lo, hi = cfg.domain_rand.friction_range
             bucket_ids = torch.randint(0, 64, (N, 1))
@@ -52,6 +53,7 @@ def draw_env_constants(cfg, num_envs_total, body0_mass, terrain):
         if cfg.domain_rand.randomize_base_mass:
             lo, hi = cfg.domain_rand.added_mass_range
             dmass[i] = np.random.uniform(lo, hi)
+    out["start_pos"] = start
     out["friction"] = friction
     out["base_mass_delta"] = torch.from_numpy((body0_mass + dmass).astype(np.float32) - np.float32(body0_mass))
     out["base_mass"] = body0_mass + dmass
@@ -96,6 +98,9 @@ class LeggedRobot(BaseTask):
         t = self.core.t
         lo, hi = rank * self.num_envs, (rank + 1) * self.num_envs
         t["env_origins"].copy_(consts["env_origins"][lo:hi])
+        # the pose create_actor leaves in root_states until the first reset: the terrain curriculum of reset() measures the
+        # distance walked from it (legged_robot.py:472-475: init_done is already True there)
+        t["root_states"][:, :3].copy_(consts["start_pos"][lo:hi])
         t["friction"].copy_(consts["friction"][lo:hi])
         t["base_mass_delta"].copy_(consts["base_mass_delta"][lo:hi])
         self.fault_total, self.n_fault = t["fault_total"], t["n_fault"]
@@ -186,7 +191,7 @@ class LeggedRobot(BaseTask):
         if n == 0:
             return
         self.core.lib.lg_set_init_done(self.core.ctx, int(self.init_done))
-        if n == self.num_envs:
+        if n == self.num_envs and bool((ids == torch.arange(n, device=self.device)).all()):
             self.core.call("reset_all")               # reset_idx(arange(N)) of BaseTask.reset(): no episode logging needed
             return
         self._reset_ids = ids.to(torch.int32).contiguous()    # kept alive until the next call (the launch is asynchronous)

@@ -61,6 +61,8 @@ def _declare_ppo(lib):
     lib.lg_ppo_minibatch_step.argtypes = [vp]
     lib.lg_ppo_end_update.argtypes = [vp]
     lib.lg_ppo_act_inference.argtypes = [vp, vp, vp, C.c_int64]
+    lib.lg_ppo_params_changed.argtypes = [vp]
+    lib.lg_ppo_debug_bucket_extents.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 
 
 _TORCH_DT = {"f4": "float32", "u1": "uint8", "i8": "int64", "i4": "int32"}

@@ -69,8 +69,9 @@ class NativeComm:
         if self.world_size == 1:
             return self.new_unique_id()
         if store is None:
-            store = torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]) + 1,
-                                               self.world_size, is_master=self.rank == 0)
+            # LG_COMM_PORT: the launcher picks a free port for the id exchange (bench.py does); else MASTER_PORT + 1
+            port = int(os.environ["LG_COMM_PORT"]) if "LG_COMM_PORT" in os.environ else int(os.environ["MASTER_PORT"]) + 1
+            store = torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, self.world_size, is_master=self.rank == 0)
         if self.rank == 0:
             uid = self.new_unique_id()
             store.set("lg_comm_id", uid)

@@ -98,6 +98,7 @@ class HipPPO:
             self.param_views[name] = self.t["params"][int(offs[k]):int(offs[k]) + size].view(view_shape)
             self.grad_views[name] = self.t["grads"][int(offs[k]):int(offs[k]) + size].view(view_shape)
         self._init_parameters(ah, ch)
+        self.params_changed()
         self.use_current_stream()
 
     # nn.Linear default initialisation, drawn in the order rsl_rl's ActorCritic constructs its layers
@@ -170,6 +171,12 @@ class HipPPO:
     def load_state_dict(self, sd):
         for k, v in sd.items():
             self.param_views[k].copy_(v.to(self.device))
+        self.params_changed()
+
+    def params_changed(self):
+        """Call after writing parameters through ``param_views`` / ``t["params"]``: the rollout's weight images are re-derived
+        by the next act() (also in the middle of a rollout)."""
+        self.lib.lg_ppo_params_changed(self.ctx)
 
     def optimizer_state_dict(self):
         """torch.optim.Adam.state_dict() layout over ActorCritic.parameters() order (rl/checkpoint.py)."""

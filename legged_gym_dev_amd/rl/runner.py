@@ -98,6 +98,7 @@ class OnPolicyRunner:
         if self.comm:                                 # identical initial policy on every rank
             torch.cuda.synchronize()
             self.comm.broadcast(self.ppo.t["params"], src=0)
+            self.ppo.params_changed()
             if hasattr(self.comm, "attach"):
                 self.comm.attach(self.ppo)            # NativeComm: gradients reduced inside the backward pass from here on
         self.log_dir = log_dir
@@ -159,8 +160,10 @@ class OnPolicyRunner:
         self.last_fps = fps
         # rsl_rl bookkeeping, kept on the device by k_process_step / k_finalize and fetched once per iteration:
         # rewbuffer / lenbuffer = the last 100 finished episodes; ep_infos = infos["episode"] of every step, averaged
-        ring, cnt = ppo.t["ep_ring"].cpu(), int(ppo.t["ep_ring_count"].cpu())
-        k = min(cnt, 100)
+        # (the device counter is a free-running uint32: slot = count % 100; once 100 episodes have finished the ring stays full)
+        ring, cnt = ppo.t["ep_ring"].cpu(), int(ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
+        self._ring_full = getattr(self, "_ring_full", False) or cnt >= 100
+        k = 100 if self._ring_full else cnt
         self.rewbuffer, self.lenbuffer = deque(ring[0, :k].tolist(), maxlen=100), deque(ring[1, :k].tolist(), maxlen=100)
         ppo.t["ep_stats"].zero_()
         mean_std = float(ppo.param_views["std"].mean())

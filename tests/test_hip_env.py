@@ -590,6 +590,77 @@ def test_rough_terrain_shards_equal_the_unsharded_run():
             s.close()
 
 
+def test_baseline_config3_eight_shards_equal_unsharded_32768():
+    """BASELINE.json configs[3] at FULL size on one GPU: anymal_c_rough, 32 768 envs on the reference's 10 x 20 tile terrain,
+    built once as a single context and once as ranks 0..7 of 8 x 4096 the way a rank builds its shard
+    (LeggedRobot(rank=r, world_size=8): per-env constants drawn for the global range and sliced, Philox keyed by the global
+    env id).  terrain_types = floor(i / (N_total / num_cols)) on the GLOBAL index (legged_robot.py:801-803); levels, origins,
+    friction and base mass equal slice by slice; 12 policy steps bit-equal for obs, rew, reset, time_out, terrain_levels,
+    measured_heights and the state, with time-outs, falls and curriculum moves (envs displaced past half a tile move up and
+    wrap to a random level at the top row); the physics fault guard never fires."""
+    import torch
+    W, n = 8, 4096
+    N = W * n
+    full = _product_env("anymal_c_rough", N, terrain=None)
+    sh = []
+    try:
+        t = full.core.t
+        assert full.terrain.heightsamples.shape == (1300, 2100) and full.cfg.terrain.num_cols == 20
+        want_types = torch.div(torch.arange(N), N / 20, rounding_mode="floor").long()
+        assert torch.equal(t["terrain_types"].cpu(), want_types)
+        lv_init = t["terrain_levels"].clone()
+        full.reset()
+        g = torch.Generator(device="cuda").manual_seed(11)
+        ep = torch.randint(0, 1001, (N,), device="cuda", generator=g)
+        mover = (torch.arange(N, device="cuda") % 97) == 0              # walked 4.5 m: level up at its time-out
+        ep[mover] = 1001
+        shift = torch.zeros(N, 13, device="cuda")
+        shift[mover, 0] = 4.5
+        full.episode_length_buf = ep
+        t["root_states"].add_(shift)
+        lv0 = t["terrain_levels"].clone()
+        acts = [torch.randn(N, 12, device="cuda", generator=g) * (2.0 if s % 5 == 3 else 0.6) for s in range(12)]
+        names = ("obs", "rew", "reset", "time_out", "terrain_levels", "env_origins", "measured_heights", "root_states", "dof_state",
+                 "commands", "episode_length", "contact_forces")
+        want = []
+        n_reset = 0
+        for a in acts:
+            full.step(a)
+            want.append({k: t[k].clone() for k in names})
+            n_reset += int(t["n_reset"][0])
+        moved = int((t["terrain_levels"] != lv0).sum())
+        wrapped = int(((lv0 == 9) & mover & (t["terrain_levels"] != 9)).sum())
+        assert n_reset >= 300 and moved >= 300 and wrapped > 0, (n_reset, moved, wrapped)
+        assert int(t["fault_total"][0]) == 0
+        consts = {k: t[k].clone() for k in ("terrain_types", "env_origins", "friction", "base_mass_delta")}
+        for r in range(W):
+            s = _product_env("anymal_c_rough", n, rank=r, world=W, terrain=None)
+            sh.append(s)
+            lo, hi = r * n, (r + 1) * n
+            st = s.core.t
+            assert int(s.setup.env_offset) == lo and int(s.setup.total_envs) == N
+            assert torch.equal(st["terrain_types"], consts["terrain_types"][lo:hi]), f"rank {r} terrain_types"
+            assert torch.equal(st["terrain_levels"], lv_init[lo:hi]), f"rank {r} initial levels"
+            for k in ("friction", "base_mass_delta"):
+                assert torch.equal(st[k], consts[k][lo:hi]), f"rank {r} {k}"
+            s.reset()
+            s.episode_length_buf = ep[lo:hi]
+            st["root_states"].add_(shift[lo:hi])
+            resets = 0
+            for step, a in enumerate(acts):
+                s.step(a[lo:hi].contiguous())
+                for k in names:
+                    assert torch.equal(st[k], want[step][k][lo:hi]), f"rank {r} step {step} {k}"
+                resets += int(st["n_reset"][0])
+            assert int(st["fault_total"][0]) == 0
+            s.close()
+            sh.pop()
+    finally:
+        full.close()
+        for s in sh:
+            s.close()
+
+
 @pytest.mark.parametrize("task,z_lo,z_hi", [("anymal_c_rough", -3.0, 6.0), ("cassie", -3.0, 6.0)])
 def test_rollout_properties_at_baseline_size_on_terrain(task, z_lo, z_hi):
     """BASELINE.json configs[2] / configs[4] sizes: 4096 envs on the reference's full 10 x 20 tile terrain (1300 x 2100

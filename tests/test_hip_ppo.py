@@ -112,13 +112,15 @@ def test_philox_sampling_is_standard_normal():
     hip.close()
 
 
-@pytest.mark.parametrize("O", [48, 235, 169, 65])
-def test_returns_and_gradients_match_torch(O):
+@pytest.mark.parametrize("O,hidden", [(48, None), (235, None), (169, None), (65, None), (48, [128, 64, 32])])
+def test_returns_and_gradients_match_torch(O, hidden):
     """O: the observation widths of the four tasks.  235, 169 and 65 are not multiples of 8: the minibatch gathers and the
     first layer's weight planes then carry zero pad columns (rows of 240 / 176 / 72) and the first layer's weight gradient is
-    computed on the padded width and stored on the true one."""
+    computed on the padded width and stored on the true one.  hidden = [128, 64, 32]: the reference's own flat-task policy
+    (anymal_c_flat_config.py:62-65), whose 32-wide last hidden layer takes the k_head_fused<32> path."""
     N, A, T = 512, 12, 8
-    hip, ac, pt = _make(N, O, A, T)
+    pol = POLICY if hidden is None else dict(POLICY, actor_hidden_dims=hidden, critic_hidden_dims=hidden)
+    hip, ac, pt = _make(N, O, A, T, pol)
     g = torch.Generator(device="cuda").manual_seed(2)
     rec = _fill_rollout(hip, ac, T, N, O, A, g)
     last_obs = torch.randn(N, O, device="cuda", generator=g)
@@ -395,8 +397,10 @@ def test_other_activations_forward_and_gradients(activation):
         hip.close()
 
 
-def test_two_rank_update_equals_single_process_update():
-    """SURVEY.md §8(e) without a second GPU: two HipPPO shards (world_size 2, 64 envs each) whose `all_reduce` is
+@pytest.mark.parametrize("W", [2, 8])
+def test_two_rank_update_equals_single_process_update(W):
+    """SURVEY.md §8(e) without a second GPU: W HipPPO shards (world_size 2 with 64 envs each; world_size 8 -- BASELINE
+    configs[3]'s rank count -- with 16 each) whose `all_reduce` is
     emulated by summing their buffers in-process, against one HipPPO over the 128 envs.  One minibatch per epoch, so both
     sides average over the same samples: global advantage normalisation (3-float moment reduce), [gradient | KL] reduce,
     /world in the optimiser kernels, KL-adaptive lr and Adam must leave all three with the same parameters
@@ -407,7 +411,8 @@ def test_two_rank_update_equals_single_process_update():
     alg = dict(ALG, num_mini_batches=1, num_learning_epochs=2)
     torch.manual_seed(5)
     one = HipPPO(N, O, None, A, policy, alg, T, device="cuda:0", seed=5)
-    sh = [HipPPO(N // 2, O, None, A, policy, alg, T, device="cuda:0", seed=5, world_size=2, rank=r) for r in range(2)]
+    n = N // W
+    sh = [HipPPO(n, O, None, A, policy, alg, T, device="cuda:0", seed=5, world_size=W, rank=r) for r in range(W)]
     try:
         sd = {k: v.clone() for k, v in one.state_dict().items()}
         for s in sh:
@@ -421,7 +426,7 @@ def test_two_rank_update_equals_single_process_update():
             rew = torch.randn(N, device="cuda", generator=g)
             dones = (torch.rand(N, device="cuda", generator=g) < 0.1).to(torch.uint8)
             tos = ((torch.rand(N, device="cuda", generator=g) < 0.5) & (dones > 0)).to(torch.uint8)
-            for p, sl in ((one, slice(0, N)), (sh[0], slice(0, N // 2)), (sh[1], slice(N // 2, N))):
+            for p, sl in [(one, slice(0, N))] + [(sh[r], slice(r * n, (r + 1) * n)) for r in range(W)]:
                 p.t["noise"].copy_(noise[sl])
                 p.act(obs[sl].contiguous())
                 p.process_env_step(rew[sl].contiguous(), dones[sl].contiguous(), {"time_outs": tos[sl].contiguous()})
@@ -429,19 +434,21 @@ def test_two_rank_update_equals_single_process_update():
 
         def reduce_over_shards(name, n=None):
             def f(_view):
-                tot = sh[0].t[name][:n] + sh[1].t[name][:n]
+                tot = sh[0].t[name][:n].clone()
+                for s in sh[1:]:
+                    tot += s.t[name][:n]
                 for s in sh:
                     s.t[name][:n].copy_(tot)
             return f
         one.compute_returns(last)
         # shards: the collective is called once per rank on its own view; emulate by summing after both have produced theirs
         for r, s in enumerate(sh):
-            s._call("compute_returns", __import__("ctypes").c_void_p(last[r * N // 2:(r + 1) * N // 2].contiguous().data_ptr()))
+            s._call("compute_returns", __import__("ctypes").c_void_p(last[r * n:(r + 1) * n].contiguous().data_ptr()))
         torch.cuda.synchronize()
         reduce_over_shards("adv_partial")(None)
         for s in sh:
             s._call("normalize_advantages")
-        torch.testing.assert_close(torch.cat([sh[0].t["advantages"], sh[1].t["advantages"]], dim=1), one.t["advantages"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(torch.cat([s.t["advantages"] for s in sh], dim=1), one.t["advantages"], rtol=1e-5, atol=1e-6)
         one.update()
         for s in sh:
             s._call("begin_update")
@@ -459,7 +466,8 @@ def test_two_rank_update_equals_single_process_update():
         for s in sh:
             torch.testing.assert_close(s.t["params"][: s.num_params], ref, rtol=2e-4, atol=2e-6)
             assert abs(s.learning_rate - one.learning_rate) < 1e-12
-        assert torch.equal(sh[0].t["params"], sh[1].t["params"])          # ranks stay in lock-step exactly
+        for s in sh[1:]:
+            assert torch.equal(sh[0].t["params"], s.t["params"])          # ranks stay in lock-step exactly
     finally:
         one.close()
         for s in sh:
@@ -552,3 +560,54 @@ def test_native_rccl_comm_single_rank():
         assert rel < 2e-4, rel
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("hidden", [[512, 256, 128], [128, 64, 32], [96, 40]])
+def test_gradient_buckets_tile_the_reduce_buffer(hidden):
+    """The overlapped RCCL reduction (lg_ppo_set_comm) sends one bucket per layer: W, b of both nets, and with the head's
+    bucket std and the [KL | pad] tail.  Host-side check of the extents it hands to RCCL: over all layers they cover
+    grads[0 : num_reduce) exactly once -- no gap, no overlap -- for the per-layer head ([96, 40]) and both fused-head widths.
+    (With one rank every collective is the identity, so a wrong extent would pass every numerical test here: world > 1 of the
+    native path is parity-unpinned on this one-GPU box)"""
+    import ctypes as C
+    pol = dict(POLICY, actor_hidden_dims=hidden, critic_hidden_dims=hidden)
+    hip, _, _ = _make(64, 235, 12, 4, pol)
+    try:
+        cover = np.zeros(hip.num_reduce, np.int32)
+        offs, cnts = (C.c_int64 * 4)(), (C.c_int64 * 4)()
+        nl = len(hidden) + 1
+        for l in range(nl):
+            n = hip.lib.lg_ppo_debug_bucket_extents(hip.ctx, l, offs, cnts)
+            assert n == (4 if l == nl - 1 else 2)
+            for k in range(n):
+                assert 0 <= offs[k] and offs[k] + cnts[k] <= hip.num_reduce
+                cover[offs[k]:offs[k] + cnts[k]] += 1
+        assert hip.lib.lg_ppo_debug_bucket_extents(hip.ctx, nl, offs, cnts) == -1
+        assert (cover == 1).all(), (int((cover == 0).sum()), int((cover > 1).sum()))
+    finally:
+        hip.close()
+
+
+def test_parameter_write_in_the_middle_of_a_rollout_reaches_act():
+    """The one-launch act reads a fragment-order image of the weights: after load_state_dict() between two act() calls of one
+    rollout (runner.load, a broadcast) the next act must sample from the NEW actor -- the image is rebuilt whenever the
+    parameters were announced changed, not only at the first step of a rollout."""
+    N, O, A, T = 256, 48, 12, 6
+    hip, ac, pt = _make(N, O, A, T)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(9)
+        obs = torch.randn(N, O, device="cuda", generator=g)
+        hip.act(obs)
+        mu0 = hip.t["act_mu"].clone()
+        hip.process_env_step(torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"), {})
+        sd = {k: v * 0.5 for k, v in hip.state_dict().items()}
+        hip.load_state_dict(sd)
+        ac.load_state_dict(sd)
+        hip.act(obs)                                            # step 1 of the same rollout
+        with torch.no_grad():
+            want = ac.actor(obs)
+        assert float((want - mu0).abs().max()) > 1e-3
+        torch.testing.assert_close(hip.t["act_mu"], want, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(hip.act_inference(obs), want, rtol=2e-5, atol=2e-5)
+    finally:
+        hip.close()
