@@ -227,7 +227,29 @@ typedef struct lg_buffers {
     float *push_timer;                    /* (N) time_until_next_push (:150-160) */
     float *inject_uniforms;               /* (N, K) or unused */
     int64_t *inject_levels;               /* N */
+    float *material;                      /* (N, 4) per-env randomised shape / body properties beside friction and base mass:
+                                             [restitution, compliance, thickness, inverse base mass] (legged_robot.py:284-299,337-339);
+                                             zeros = the asset's defaults */
 } lg_buffers;
+
+/* ---- Staged curriculum (legged_robot.py:360-363,488-505 base env: command ranges, push magnitude / period;
+ * legged_robot_trajectory.py:414-417,519-553 trajectory env: reward scales, tracking sigma, ROM input bounds, hold-time sampler,
+ * start-offset range).  The stage machine itself (curriculum_state, `common_step_counter % curriculum_steps[state] == 0`) is host
+ * logic, as in the reference; a stage change rewrites these device constants.  In the reference the change happens at the END of
+ * _post_physics_step_callback of the step that triggers it: the callback's own command resample / push / generator resample still
+ * see the old values, everything after it (rewards, resets, observations of the same step) the new ones.
+ * lg_set_curriculum_stage(.., in_callback = 1) reproduces exactly that for the next lg_step / lg_post_physics_step;
+ * in_callback = 0 applies at once (the update at construction, legged_robot.py:828-829 / legged_robot_trajectory.py:78-79). */
+typedef struct lg_stage {
+    float cmd_lo[4], cmd_hi[4];           /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading */
+    float max_push_vel, _pad;
+    double push_time;                     /* policy steps between pushes; may be fractional (nominal x multiplier): a push fires when
+                                             step_counter % push_time == 0 in Python float arithmetic */
+    float rew_scale[LG_NUM_REWARDS];      /* x dt, as lg_cfg.rew_scale */
+    float xterm_scale[LG_MAX_XTERMS];     /* x dt, as lg_xterm.scale */
+    float xterm_p0[LG_MAX_XTERMS];        /* lg_xterm.p[0] (tracking_rom: its sigma) */
+    float traj_v_min[2], traj_v_max[2], traj_t_low, traj_t_high, traj_max_rom_dist[2];
+} lg_stage;
 
 typedef struct lg_ctx lg_ctx;
 
@@ -266,6 +288,8 @@ int lg_reset_all(lg_ctx *ctx);                                 /* reset_idx(aran
  * over the ids and extras["time_outs"].  ids: DEVICE int32[n], local env indices, no duplicates.  n == 0 returns at once
  * (legged_robot.py:156-157).  Draws come from the env's reset slots at the current step counter. */
 int lg_reset_ids(lg_ctx *ctx, const int32_t *ids, int n);
+int lg_get_stage(lg_ctx *ctx, lg_stage *out);          /* the values in force (at creation: what lg_cfg holds) */
+int lg_set_curriculum_stage(lg_ctx *ctx, const lg_stage *stage, int in_callback);
 
 /* ------------------------------------------------------------------ PPO (rsl_rl v1.0.2 semantics,
  * SURVEY.md Appendix B; call sites task_registry.py:148-155, scripts/train.py:44) */

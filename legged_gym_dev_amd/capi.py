@@ -114,11 +114,19 @@ _BUF_FIELDS = [
     ("friction", PF), ("base_mass_delta", PF), ("extras_episode", PF), ("extras_terrain_level", PF),
     ("extras_time_outs", PU8), ("extras_episode_acc", PF), ("n_reset", PI32), ("n_fault", PI32), ("fault_total", PI64),
     ("tg_state", PF), ("tg_traj", PF), ("trajectory", PF), ("prev_error", PF), ("push_timer", PF),
-    ("inject_uniforms", PF), ("inject_levels", PI64)]
+    ("inject_uniforms", PF), ("inject_levels", PI64), ("material", PF)]
 
 
 class lg_buffers(C.Structure):
     _fields_ = _BUF_FIELDS
+
+
+class lg_stage(C.Structure):
+    """Constants a curriculum stage rewrites (include/legged_hip.h lg_stage)."""
+    _fields_ = [("cmd_lo", f32 * 4), ("cmd_hi", f32 * 4), ("max_push_vel", f32), ("_pad", f32), ("push_time", C.c_double),
+                ("rew_scale", f32 * NUM_REWARDS), ("xterm_scale", f32 * MAX_XTERMS), ("xterm_p0", f32 * MAX_XTERMS),
+                ("traj_v_min", f32 * 2), ("traj_v_max", f32 * 2), ("traj_t_low", f32), ("traj_t_high", f32),
+                ("traj_max_rom_dist", f32 * 2)]
 
 
 def buffer_shapes(N, A, B, O, F, H, traj_N=0, traj_dN=1):
@@ -140,7 +148,7 @@ def buffer_shapes(N, A, B, O, F, H, traj_N=0, traj_dN=1):
         "extras_terrain_level": ((1,), "f4"), "extras_time_outs": ((N,), "u1"),
         "extras_episode_acc": ((NUM_TERMS + 2,), "f4"), "n_reset": ((1,), "i4"),
         "n_fault": ((1,), "i4"), "fault_total": ((1,), "i8"),
-        "inject_uniforms": ((N, K), "f4"), "inject_levels": ((N,), "i8")}
+        "inject_uniforms": ((N, K), "f4"), "inject_levels": ((N,), "i8"), "material": ((N, 4), "f4")}
 
 
 class lg_ppo_cfg(C.Structure):
@@ -184,6 +192,8 @@ def declare_env_api(lib, prefix="lg_"):
     for n in ("compute_torques", "simulate", "post_physics_step", "reset_all"):
         g(n).argtypes = [vp]
     g("reset_ids").argtypes = [vp, vp, C.c_int]
+    g("get_stage").argtypes = [vp, C.POINTER(lg_stage)]
+    g("set_curriculum_stage").argtypes = [vp, C.POINTER(lg_stage), C.c_int]
     if prefix == "lg_":
         g("set_stream").argtypes = [vp, vp]
         lib.lg_version.restype = C.c_int
@@ -191,7 +201,7 @@ def declare_env_api(lib, prefix="lg_"):
 
 ENV_SYMBOLS = ["last_error", "create", "destroy", "get_buffers", "set_step_counter", "get_step_counter",
                "set_init_done", "inject_uniforms", "step", "set_actions", "compute_torques", "simulate",
-               "post_physics_step", "reset_all", "reset_ids"]
+               "post_physics_step", "reset_all", "reset_ids", "get_stage", "set_curriculum_stage"]
 PPO_SYMBOLS = ["ppo_create", "ppo_destroy", "ppo_get_buffers", "ppo_set_stream", "ppo_param_layout",
                "ppo_inject_noise", "ppo_act", "ppo_process_env_step", "ppo_compute_returns",
                "ppo_normalize_advantages", "ppo_begin_update", "ppo_minibatch_backward", "ppo_minibatch_step",

@@ -1,4 +1,5 @@
 // C-ABI (include/legged_hip.h) for the environment step: context, HBM allocation, launches.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -10,7 +11,8 @@ void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
 extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s);
-extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, hipStream_t s);
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, int push_now, hipStream_t s);
+extern "C" void lgk_set_stage(DevParams *P, const lg_stage *st, int what, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
 extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int N, int64_t counter, int inject, int init_done, int traj,
                               hipStream_t s);
@@ -97,6 +99,23 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     h.model = *model;
     h.cfg.noise_vec = h.cfg.height_points = h.cfg.terrain_origins = nullptr;
     h.K = (cfg->traj.enabled ? LG_TSLOT_NOISE(A) : LG_SLOT_NOISE(A)) + O;
+    {   // the stage in force = what the cfg holds
+        lg_stage &s = c->stage;
+        memset(&s, 0, sizeof(s));
+        memcpy(s.cmd_lo, cfg->cmd_lo, sizeof(s.cmd_lo)); memcpy(s.cmd_hi, cfg->cmd_hi, sizeof(s.cmd_hi));
+        s.max_push_vel = cfg->max_push_vel;
+        s.push_time = (double)cfg->push_interval;
+        memcpy(s.rew_scale, cfg->rew_scale, sizeof(s.rew_scale));
+        for (int k = 0; k < LG_MAX_XTERMS; ++k) { s.xterm_scale[k] = cfg->xterms[k].scale; s.xterm_p0[k] = cfg->xterms[k].p[0]; }
+        memcpy(s.traj_v_min, cfg->traj.v_min, 8); memcpy(s.traj_v_max, cfg->traj.v_max, 8);
+        s.traj_t_low = cfg->traj.t_low; s.traj_t_high = cfg->traj.t_high;
+        memcpy(s.traj_max_rom_dist, cfg->traj.max_rom_dist, 8);
+        StageCb &b = h.cb;
+        memcpy(b.cmd_lo, s.cmd_lo, sizeof(b.cmd_lo)); memcpy(b.cmd_hi, s.cmd_hi, sizeof(b.cmd_hi));
+        b.max_push_vel = s.max_push_vel;
+        memcpy(b.v_min, s.traj_v_min, 8); memcpy(b.v_max, s.traj_v_max, 8);
+        b.t_low = s.traj_t_low; b.t_high = s.traj_t_high;
+    }
 
     // sphere slots per leg (same link pattern on every leg) + base spheres one per lane
     {
@@ -170,7 +189,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
         DA(b.tg_state, (size_t)N * LG_TG_STRIDE); DA(b.tg_traj, (size_t)N * npts * 2); DA(b.trajectory, (size_t)N * nobs * 2);
         DA(b.prev_error, (size_t)N * 2); DA(b.push_timer, N); DA(h.reset_mark, N); DA(h.dbg_cycles, 64 * 8);
     }
-    DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N);
+    DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N); DA(b.material, (size_t)N * 4);
     DA(h.ep_accum, LG_NUM_TERMS); DA(h.reset_count, 1); DA(h.fault, N);
     {   // defaults: identity quaternion, unit friction, reset flags = 1 (base_task.py:72)
         float *tmp = new float[(size_t)N * 13]();
@@ -238,9 +257,40 @@ static int run_substeps(lg_ctx *c, const float *actions, int mode, int iters) {
 }
 int lg_compute_torques(lg_ctx *c) { return run_substeps(c, c->h.buf.actions, 1 /*torque stage*/, 1); }
 int lg_simulate(lg_ctx *c) { return run_substeps(c, c->h.buf.actions, 2 /*physics stage*/, 1); }
+// a curriculum stage into the host copy of the constants (the device copy follows through k_set_stage)
+static void stage_to_host(lg_ctx *c, const lg_stage &s) {
+    lg_cfg &f = c->h.cfg;
+    memcpy(f.cmd_lo, s.cmd_lo, sizeof(f.cmd_lo)); memcpy(f.cmd_hi, s.cmd_hi, sizeof(f.cmd_hi));
+    f.max_push_vel = s.max_push_vel;
+    memcpy(f.rew_scale, s.rew_scale, sizeof(f.rew_scale));
+    for (int k = 0; k < LG_MAX_XTERMS; ++k) { f.xterms[k].scale = s.xterm_scale[k]; f.xterms[k].p[0] = s.xterm_p0[k]; }
+    memcpy(f.traj.v_min, s.traj_v_min, 8); memcpy(f.traj.v_max, s.traj_v_max, 8); memcpy(f.traj.max_rom_dist, s.traj_max_rom_dist, 8);
+    f.traj.t_low = s.traj_t_low; f.traj.t_high = s.traj_t_high;
+    c->stage = s;
+}
+int lg_get_stage(lg_ctx *c, lg_stage *out) { if (!c || !out) return -1; *out = c->has_pending ? c->pending : c->stage; return 0; }
+int lg_set_curriculum_stage(lg_ctx *c, const lg_stage *s, int in_callback) {
+    if (!c || !s) { g_err = "null argument"; return -1; }
+    if (!(s->push_time >= 0.0)) { g_err = "lg_stage.push_time must be >= 0"; return -1; }
+    if (in_callback) { c->pending = *s; c->has_pending = 1; return 0; }   // applied by the next lg_post_physics_step
+    c->has_pending = 0;
+    stage_to_host(c, *s);
+    lgk_set_stage(c->d, s, 3, c->stream);
+    return chk_launch();
+}
 int lg_post_physics_step(lg_ctx *c) {
     c->step_counter += 1;                                       // legged_robot.py:115
-    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, c->stream);
+    // legged_robot.py:358: common_step_counter % push_time == 0 on the period of the stage in force when the step began
+    // (push_time may be fractional after a curriculum multiplier: Python's float modulo)
+    const double pt = c->stage.push_time;
+    const int push_now = c->h.cfg.push_robots && pt > 0.0 && std::fmod((double)c->step_counter, pt) == 0.0;
+    if (c->has_pending) lgk_set_stage(c->d, &c->pending, 1, c->stream);          // what follows the callback sees the new stage
+    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, push_now, c->stream);
+    if (c->has_pending) {                                                        // ... and from the next step on the callback too
+        lgk_set_stage(c->d, &c->pending, 2, c->stream);
+        stage_to_host(c, c->pending);
+        c->has_pending = 0;
+    }
     return chk_launch();
 }
 int lg_reset_all(lg_ctx *c) {

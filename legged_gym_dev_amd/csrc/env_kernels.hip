@@ -306,14 +306,15 @@ __device__ __forceinline__ float uni(const DevParams *P, int env, int slot, int6
     return philox_uniform(P->cfg.seed, (uint32_t)(P->cfg.env_offset + env), (uint64_t)counter, (uint32_t)slot);
 }
 
-__device__ void resample_commands(const DevParams *P, int i, int slot0, int64_t counter, int inject) {   // LR:365-387
+// lo / hi: the command ranges in force -- cfg.cmd_* for a reset env, cb.cmd_* inside the step callback (lg_device.h StageCb)
+__device__ void resample_commands(const DevParams *P, int i, int slot0, int64_t counter, int inject, const float *lo, const float *hi) {   // LR:365-387
     const lg_cfg &c = P->cfg;
     float *cmd = P->buf.commands + (size_t)i * 4;
-    float c0 = (c.cmd_hi[0] - c.cmd_lo[0]) * uni(P, i, slot0 + 0, counter, inject) + c.cmd_lo[0];
-    float c1 = (c.cmd_hi[1] - c.cmd_lo[1]) * uni(P, i, slot0 + 1, counter, inject) + c.cmd_lo[1];
+    float c0 = (hi[0] - lo[0]) * uni(P, i, slot0 + 0, counter, inject) + lo[0];
+    float c1 = (hi[1] - lo[1]) * uni(P, i, slot0 + 1, counter, inject) + lo[1];
     float u2 = uni(P, i, slot0 + 2, counter, inject);
-    if (c.heading_command) cmd[3] = (c.cmd_hi[3] - c.cmd_lo[3]) * u2 + c.cmd_lo[3];
-    else cmd[2] = (c.cmd_hi[2] - c.cmd_lo[2]) * u2 + c.cmd_lo[2];
+    if (c.heading_command) cmd[3] = (hi[3] - lo[3]) * u2 + lo[3];
+    else cmd[2] = (hi[2] - lo[2]) * u2 + lo[2];
     float keep = sqrtf(c0 * c0 + c1 * c1) > 0.2f ? 1.0f : 0.0f;
     cmd[0] = c0 * keep;
     cmd[1] = c1 * keep;
@@ -513,7 +514,7 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
         for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(P, i, s_xy + k, counter, inject) + (-1.0f);
     for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(P, i, s_vel + k, counter, inject) + (-0.5f);
     if (tj) reset_trajectory(P, i, counter, inject);
-    else resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
+    else resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject, c.cmd_lo, c.cmd_hi);
     for (int j = 0; j < A; ++j) { P->buf.last_actions[(size_t)i * A + j] = 0.0f; P->buf.last_dof_vel[(size_t)i * A + j] = 0.0f; }
     for (int f = 0; f < c.num_feet; ++f) P->buf.feet_air_time[(size_t)i * c.num_feet + f] = 0.0f;
     P->buf.episode_length[i] = 0;
@@ -574,7 +575,7 @@ __device__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int i
         if (k >= 7) v = (0.5f - (-0.5f)) * uni(P, i, s_vel + (k - 7), counter, inject) + (-0.5f);
         r[k] = v;
     } else if (tid == A + 13) {
-        if (!tj) resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject);
+        if (!tj) resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject, c.cmd_lo, c.cmd_hi);
         P->buf.episode_length[i] = 0;
         P->buf.reset[i] = 1;
         P->reset_mark[i] = 1;
@@ -619,7 +620,8 @@ __device__ __forceinline__ float height_sample(const DevParams *P, const float *
 
 // The body works on one tile of TILE environments starting at env0 and touches no other environment's state.
 template <int TILE>
-__device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, const int env0, int64_t counter, int inject, int init_done) {
+__device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, const int env0, int64_t counter, int inject, int init_done,
+                                               int push_now) {
     const lg_cfg &c = P->cfg;
     const int N = c.num_envs, A = c.num_actions, B = c.num_bodies, O = c.num_obs, H = c.num_height_points;
     const int nE = min(TILE, N - env0);
@@ -764,7 +766,7 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
         const bool to = ep > c.max_episode_length;
         rst = rst || flt || to;
         if (c.traj.enabled) tg_callback_step(P, i, counter, inject);       // LT:405-417
-        else if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject);   // LR:348-350
+        else if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject, P->cb.cmd_lo, P->cb.cmd_hi);   // LR:348-350
         if (c.heading_command && !c.traj.enabled) {                         // LR:351-354, math.py:45-48
             V3 fwd = quat_apply(r + 3, V3{1.0f, 0.0f, 0.0f});
             float heading = atan2f(fwd.y, fwd.x);
@@ -783,9 +785,10 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
                 tm = (c.traj.push_t_hi - c.traj.push_t_lo) * uni(P, i, LG_TSLOT_TIMER, counter, inject) + c.traj.push_t_lo;
             }
             P->buf.push_timer[i] = tm;
-        } else if (c.push_robots && c.push_interval > 0 && (counter % c.push_interval == 0)) {   // LR:358-359,456-461
-            r[7] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH, counter, inject) + (-c.max_push_vel);
-            r[8] = (c.max_push_vel - (-c.max_push_vel)) * uni(P, i, LG_SLOT_PUSH + 1, counter, inject) + (-c.max_push_vel);
+        } else if (push_now) {                                              // LR:358-359,456-461 (the period check is the host's: lg_stage.push_time)
+            const float mv = P->cb.max_push_vel;
+            r[7] = (mv - (-mv)) * uni(P, i, LG_SLOT_PUSH, counter, inject) + (-mv);
+            r[8] = (mv - (-mv)) * uni(P, i, LG_SLOT_PUSH + 1, counter, inject) + (-mv);
         }
         x.cmd = cmd; x.cf = cf; x.root_z = r[2]; x.reset = rst; x.time_out = to;
         x.dof = P->buf.dof_state + (size_t)i * A * 2;
@@ -939,8 +942,30 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
 
 template <int TILE>
 __global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *__restrict__ P, int64_t counter, int inject,
-                                                               int init_done) {
-    post_step_tile<TILE>(P, (int)blockIdx.x * TILE, counter, inject, init_done);
+                                                               int init_done, int push_now) {
+    post_step_tile<TILE>(P, (int)blockIdx.x * TILE, counter, inject, init_done, push_now);
+}
+
+// A curriculum stage (legged_hip.h lg_stage) into the device constants.  what & 1: the values read after the step callback
+// (cfg); what & 2: the values the callback reads (cb).  One lane; stream-ordered with the step kernels.
+__global__ void k_set_stage(DevParams *P, lg_stage s, int what) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    lg_cfg &c = P->cfg;
+    if (what & 1) {
+        for (int k = 0; k < 4; ++k) { c.cmd_lo[k] = s.cmd_lo[k]; c.cmd_hi[k] = s.cmd_hi[k]; }
+        c.max_push_vel = s.max_push_vel;
+        for (int k = 0; k < LG_NUM_REWARDS; ++k) c.rew_scale[k] = s.rew_scale[k];
+        for (int k = 0; k < LG_MAX_XTERMS; ++k) { c.xterms[k].scale = s.xterm_scale[k]; c.xterms[k].p[0] = s.xterm_p0[k]; }
+        for (int k = 0; k < 2; ++k) { c.traj.v_min[k] = s.traj_v_min[k]; c.traj.v_max[k] = s.traj_v_max[k]; c.traj.max_rom_dist[k] = s.traj_max_rom_dist[k]; }
+        c.traj.t_low = s.traj_t_low; c.traj.t_high = s.traj_t_high;
+    }
+    if (what & 2) {
+        StageCb &b = P->cb;
+        for (int k = 0; k < 4; ++k) { b.cmd_lo[k] = s.cmd_lo[k]; b.cmd_hi[k] = s.cmd_hi[k]; }
+        b.max_push_vel = s.max_push_vel;
+        for (int k = 0; k < 2; ++k) { b.v_min[k] = s.traj_v_min[k]; b.v_max[k] = s.traj_v_max[k]; }
+        b.t_low = s.traj_t_low; b.t_high = s.traj_t_high;
+    }
 }
 
 // Single-workgroup epilogue: extras["episode"], extras["time_outs"] (only refreshed when >=1 env
@@ -1064,9 +1089,12 @@ extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L,
     else return -1;
     return 0;
 }
-extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, hipStream_t s) {
+extern "C" void lgk_set_stage(DevParams *P, const lg_stage *st, int what, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_stage, dim3(1), dim3(64), 0, s, P, *st, what);
+}
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, int push_now, hipStream_t s) {
     constexpr int TILE = 16;
-    hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done);
+    hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done, push_now);
     if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject, 1);
 }

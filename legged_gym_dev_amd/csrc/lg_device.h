@@ -39,8 +39,17 @@ static inline float lstm_lds_image(const float *__restrict__ w, int o) {
     return f == 112 ? w[LW + k] : 0.0f;
 }
 
+// What the step CALLBACK reads of a curriculum stage (legged_hip.h lg_stage): the command resample, the push and the generator
+// resample of _post_physics_step_callback see the values of the stage that was in force when the step began; everything after the
+// callback reads cfg.  Outside a stage-change step the two agree.
+struct StageCb {
+    float cmd_lo[4], cmd_hi[4];
+    float max_push_vel;
+    float v_min[2], v_max[2], t_low, t_high;
+};
 struct DevParams {
     lg_cfg cfg;          // host pointers inside are NOT valid on device (use the ones below)
+    StageCb cb;
     lg_model model;
     lg_buffers buf;
     const float *noise_vec;        // num_obs
@@ -76,6 +85,8 @@ struct lg_ctx {
     hipStream_t stream;
     int64_t step_counter;
     int init_done, inject;
+    lg_stage stage, pending;  // curriculum stage in force / to take effect inside the next post-step's callback
+    int has_pending;
     void *allocs[128];
     int n_allocs;
 };

@@ -13,10 +13,20 @@ __device__ __forceinline__ float tg_uni(const DevParams *P, int env, int slot, i
     return philox_uniform(P->cfg.seed, (uint32_t)(P->cfg.env_offset + env), (uint64_t)counter, (uint32_t)slot);
 }
 
+// the generator parameters a curriculum stage rewrites (LT:533-546): ROM input bounds and the hold-time sampler
+struct TgPar { float v_min[2], v_max[2], t_low, t_high, freq_low, freq_high, prob_stationary; };
+__device__ __forceinline__ TgPar tg_par_cfg(const DevParams *P) {          // the values in force after the step callback
+    const lg_traj_cfg &c = P->cfg.traj;
+    return {{c.v_min[0], c.v_min[1]}, {c.v_max[0], c.v_max[1]}, c.t_low, c.t_high, c.freq_low, c.freq_high, c.prob_stationary};
+}
+__device__ __forceinline__ TgPar tg_par_cb(const DevParams *P) {           // ... inside the callback (lg_device.h StageCb)
+    const lg_traj_cfg &c = P->cfg.traj;
+    const StageCb &b = P->cb;
+    return {{b.v_min[0], b.v_min[1]}, {b.v_max[0], b.v_max[1]}, b.t_low, b.t_high, c.freq_low, c.freq_high, c.prob_stationary};
+}
 // RD:507-515
-__device__ inline void tg_resample(const DevParams *P, int i, int slot0, int64_t counter, int inject) {
+__device__ inline void tg_resample(const DevParams *P, const TgPar &t, int i, int slot0, int64_t counter, int inject) {
 #pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
-    const lg_traj_cfg &t = P->cfg.traj;
     float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
     const float pi = 3.14159265358979323846f;
 #pragma unroll
@@ -128,7 +138,7 @@ __device__ inline void tg_callback_step(const DevParams *P, int i, int64_t count
     TgWindow w;
     tg_window_load(P, i, w);
     const float tt = s[LG_TG_T];
-    if (tt > s[LG_TG_T_FINAL]) tg_resample(P, i, LG_TSLOT_TG, counter, inject);
+    if (tt > s[LG_TG_T_FINAL]) tg_resample(P, tg_par_cb(P), i, LG_TSLOT_TG, counter, inject);
     float v[2];
     tg_input(P, i, tt, v);
     float k = s[LG_TG_K];
@@ -157,7 +167,7 @@ __device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y,
     s[LG_TG_K] = -(float)(t.N * t.dN);
     s[LG_TG_T] = s[LG_TG_K] * t.rom_dt;
     s[LG_TG_T_FINAL] = s[LG_TG_K] * t.rom_dt;
-    tg_resample(P, i, LG_TSLOT_RTG(A), counter, inject);
+    tg_resample(P, tg_par_cfg(P), i, LG_TSLOT_RTG(A), counter, inject);
     float tt = s[LG_TG_T], k = s[LG_TG_K], v[2] = {0.0f, 0.0f};
     for (int it = 0; it < t.N * t.dN; ++it) {
         tg_input(P, i, tt, v);
@@ -175,7 +185,7 @@ __device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y,
 __device__ inline void tg_late_resample(const DevParams *P, int i, int64_t counter, int inject) {
 #pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
     float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
-    if (s[LG_TG_T] > s[LG_TG_T_FINAL]) tg_resample(P, i, LG_TSLOT_RTG(P->cfg.num_actions), counter, inject);
+    if (s[LG_TG_T] > s[LG_TG_T_FINAL]) tg_resample(P, tg_par_cfg(P), i, LG_TSLOT_RTG(P->cfg.num_actions), counter, inject);
     float v[2];                                                    // and leaves self.v evaluated at the env's new time
     tg_input(P, i, s[LG_TG_T], v);
     s[LG_TG_V] = v[0]; s[LG_TG_V + 1] = v[1];

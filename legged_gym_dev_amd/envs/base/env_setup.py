@@ -50,6 +50,22 @@ def load_actuator_weights(path_hint: str = "") -> np.ndarray:
     return flat
 
 
+class CurriculumClock:
+    """The reference's curriculum stage machine (legged_robot.py:360-363 / legged_robot_trajectory.py:414-417): at the end of
+    the step callback, ``if use_curriculum and state < len(curriculum_steps) and common_step_counter % curriculum_steps[state]
+    == 0: state += 1``.  Host logic there and here; the constants of a stage travel through lg_set_curriculum_stage."""
+
+    def __init__(self, setup):
+        self.enabled, self.steps, self.state = bool(setup.use_curriculum), list(setup.curriculum_steps), 0
+
+    def tick(self, common_step_counter):
+        """True when the step that carries this (already incremented) counter moves to the next stage."""
+        if self.enabled and self.state < len(self.steps) and common_step_counter % self.steps[self.state] == 0:
+            self.state += 1
+            return True
+        return False
+
+
 class EnvSetup:
     """Everything derived from (cfg, model) before any device work."""
 
@@ -74,6 +90,7 @@ class EnvSetup:
             self.command_ranges = class_to_dict(cfg.commands.ranges)
         else:                                               # the trajectory env has no commands section
             self.command_ranges = {k: [0.0, 0.0] for k in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")}
+        self.nominal_command_ranges = {k: list(v) for k, v in self.command_ranges.items()}
         self.push_time = math.ceil(cfg.domain_rand.push_interval_s / self.dt)
         self.max_push_vel = getattr(cfg.domain_rand, "max_push_vel", cfg.domain_rand.max_push_vel_xy)
         if self.traj is not None:                            # a 6-vector there, and unused: pushes draw from max_push_vel_xy (:483-486)
@@ -82,22 +99,13 @@ class EnvSetup:
             cfg.terrain.curriculum = False
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = math.ceil(self.max_episode_length_s / self.dt)
-        use_curr = getattr(getattr(cfg, "curriculum", None), "use_curriculum", False)
-        if use_curr:
-            raise NotImplementedError("command/push curriculum (cfg.curriculum.use_curriculum) is not supported")
-
-        # randomisations the reference applies in its property callbacks (legged_robot.py:284-299,337-339) that have no
-        # counterpart in this physics: refuse them rather than ignore them silently
-        dr = cfg.domain_rand
-        rsp = getattr(dr, "rigid_shape_properties", None)
-        unsupported = [n for n in ("randomize_inv_base_mass",) if getattr(dr, n, False)]
-        unsupported += [n for n in ("randomize_restitution", "randomize_compliance", "randomize_thickness")
-                        if rsp is not None and getattr(rsp, n, False)]
-        dofp = getattr(dr, "dof_properties", None)
-        unsupported += [n for n in ("randomize_stiffness", "randomize_damping", "randomize_friction", "randomize_armature")
-                        if dofp is not None and getattr(dofp, n, False)]
-        if unsupported:
-            raise NotImplementedError(f"domain_rand flags without an implementation in the HIP physics: {unsupported}")
+        # staged curriculum (legged_robot.py:360-363,488-505,828-829; legged_robot_trajectory.py:78-79,414-417,519-553)
+        cur = getattr(cfg, "curriculum", None)
+        self.use_curriculum = bool(getattr(cur, "use_curriculum", False))
+        self.curriculum_steps = [int(v) for v in getattr(cur, "curriculum_steps", [])] if self.use_curriculum else []
+        self.nominal_push_time = float(math.ceil(cfg.domain_rand.push_interval_s / self.dt))
+        # domain_rand.dof_properties.* (stiffness / damping of the hopper's joints) are read by the hopper env only
+        # (legged_gym/envs/hopper); LeggedRobot._process_dof_props (legged_robot.py:301-328) never looks at them
 
         # ---- body index sets (substring match on names)
         feet = [i for i, s in enumerate(self.body_names) if cfg.asset.foot_name in s]
@@ -227,6 +235,71 @@ class EnvSetup:
                 "zero_rom_dist_llh": float(getattr(dr, "zero_rom_distance_likelihood", 0.0)),
                 "max_push_vel_xy": float(dr.max_push_vel_xy), "push_t": [float(v) for v in dr.time_between_pushes]}
 
+    # ------------------------------------------------------------------------------ staged curriculum
+    def _nominal_push_vel(self):
+        """``_push_robots`` draws from +-self.max_push_vel as a scalar (legged_robot.py:459), ``update_command_curriculum`` iterates
+        over it as a list (:503): with the curriculum on, the reference needs the list form to get through _parse_cfg and then
+        raises at its first push.  Both forms are accepted here; the push magnitude is the (first) value."""
+        v = self.max_push_vel
+        return float(v[0]) if isinstance(v, (list, tuple)) else float(v)
+
+    def stage_values(self, ind):
+        """What ``update_command_curriculum`` leaves in the env at curriculum state ``ind`` (None: no curriculum, the nominal
+        values), as a dict of Python-side values; ``stage_struct`` packs it for lg_set_curriculum_stage.
+        Base env (legged_robot.py:488-505): command ranges x commands[ind] (heading excepted), push magnitude x
+        push.magnitude[ind], push period x push.time[ind].  Trajectory env (legged_robot_trajectory.py:519-553): reward scales
+        x rewards.<name>[ind], tracking sigma x sigma.tracking_rom[ind], ROM input bounds x rom.v[ind], hold-time sampler bounds
+        x trajectory_generator.t_low / t_high[ind], start-offset range x max_rom_distance[ind].  Reproduced as the reference
+        has them: that update also scales max_push_vel / push_time, which the trajectory env's per-env push timers never read
+        (:150-160,486-492), writes ``zero_rom_distance_likelihood`` while reset_traj reads ``zero_rom_dist_llh`` (:73,251), and
+        ignores the freq_low / freq_high / weight_sampler rows of the launch file."""
+        cfg, cur = self.cfg, getattr(self.cfg, "curriculum", None)
+        out = {"command_ranges": {k: list(v) for k, v in self.nominal_command_ranges.items()},
+               "max_push_vel": self._nominal_push_vel(), "push_time": self.nominal_push_time,
+               "reward_scales": dict(self.reward_scales), "tracking_sigma": float(getattr(cfg.rewards, "tracking_sigma", 0.25))}
+        tj = self.traj
+        if tj is not None:
+            out.update(v_min=list(tj["v_min"]), v_max=list(tj["v_max"]), t_low=tj["t_low"], t_high=tj["t_high"],
+                       max_rom_dist=list(tj["max_rom_dist"]))
+        if ind is None:
+            return out
+        out["max_push_vel"] = self._nominal_push_vel() * cur.push.magnitude[ind]
+        out["push_time"] = self.nominal_push_time * cur.push.time[ind]
+        if tj is None:
+            out["command_ranges"] = {k: [v * cur.commands[ind] if k != "heading" else v for v in val]
+                                     for k, val in self.nominal_command_ranges.items()}
+            return out
+        # torch.tensor(nominal) * multiplier (:530): a float32 product, unlike the ROM bounds below (double products, then cast)
+        out["max_rom_dist"] = [float(np.float32(v) * np.float32(cur.max_rom_distance[ind])) for v in tj["max_rom_dist"]]
+        out["v_max"] = [v * cur.rom.v[ind] for v in tj["v_max"]]
+        out["v_min"] = [v * cur.rom.v[ind] for v in tj["v_min"]]
+        out["t_low"] = tj["t_low"] * cur.trajectory_generator.t_low[ind]
+        out["t_high"] = tj["t_high"] * cur.trajectory_generator.t_high[ind]
+        out["tracking_sigma"] = out["tracking_sigma"] * cur.sigma.tracking_rom[ind]
+        for key in list(self.reward_scales.keys()):        # an active term without a row in curriculum.rewards raises, as there
+            out["reward_scales"][key] = getattr(cfg.rewards.scales, key) * getattr(cur.rewards, key)[ind] * self.dt
+        return out
+
+    def stage_struct(self, ind):
+        v = self.stage_values(ind)
+        s = capi.lg_stage()
+        for k, name in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")):
+            s.cmd_lo[k], s.cmd_hi[k] = float(v["command_ranges"][name][0]), float(v["command_ranges"][name][1])
+        s.max_push_vel, s.push_time = float(v["max_push_vel"]), float(v["push_time"])
+        for k, name in enumerate(capi.REWARD_NAMES):
+            s.rew_scale[k] = float(v["reward_scales"].get(name, 0.0))
+        for k, name in enumerate(self.xterm_names):
+            s.xterm_scale[k] = float(v["reward_scales"][name])
+            st = self.extra_terms[name].to_struct(v["reward_scales"][name])
+            s.xterm_p0[k] = st.p[0]
+            if name == "tracking_rom":                     # its sigma is env.tracking_sigma (legged_robot_trajectory.py:1069)
+                s.xterm_p0[k] = float(v["tracking_sigma"])
+        if self.traj is not None:
+            for k in range(2):
+                s.traj_v_min[k], s.traj_v_max[k], s.traj_max_rom_dist[k] = float(v["v_min"][k]), float(v["v_max"][k]), float(v["max_rom_dist"][k])
+            s.traj_t_low, s.traj_t_high = float(v["t_low"]), float(v["t_high"])
+        return s
+
     def to_structs(self):
         """(lg_cfg, lg_model, keepalive list).  Pointers in lg_cfg reference numpy arrays that
         must stay alive until lg_create returns; they are in the keepalive list."""
@@ -296,7 +369,7 @@ class EnvSetup:
         c.action_scale = cfg.control.action_scale
         c.clip_actions = cfg.normalization.clip_actions
         c.clip_obs = cfg.normalization.clip_observations
-        c.max_push_vel = float(self.max_push_vel)
+        c.max_push_vel = self._nominal_push_vel()
         c.episode_length_s = float(self.max_episode_length_s)
         r = self.command_ranges
         for k, name in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")):

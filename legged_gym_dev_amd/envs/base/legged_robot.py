@@ -16,14 +16,16 @@ from legged_gym_dev_amd.lib import HipEnvCore
 from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model
 from legged_gym_dev_amd.utils.terrain import Terrain
 from .base_task import BaseTask
-from .env_setup import EnvSetup, sim_dt_float
+from .env_setup import CurriculumClock, EnvSetup, sim_dt_float
 
 
-def draw_env_constants(cfg, num_envs_total, body0_mass, terrain):
+def draw_env_constants(cfg, num_envs_total, body0_mass, terrain, num_shapes=0):
     """Per-env constants with the reference's draw order on torch's / numpy's global CPU
     generators (``_get_env_origins`` legged_robot.py:790-817, then per env i of ``_create_envs``
     :738-751: start-pose jitter rand(2,1); at i == 0 friction buckets randint(0,64,(N,1)) and
-    rand(64,1) (:271-282); base-mass np.random.uniform (:332-334))."""
+    rand(64,1) (:271-282); then from numpy's stream, per env: for each of the asset's ``num_shapes`` rigid shapes the
+    restitution / compliance / thickness draws that are switched on (:284-299, nested under randomize_friction as there),
+    the base-mass draw (:332-334) and the inverse-base-mass draw (:337-339))."""
     N = num_envs_total
     out = {}
     if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
@@ -42,6 +44,14 @@ def draw_env_constants(cfg, num_envs_total, body0_mass, terrain):
     out["env_origins"] = origins
     friction = torch.ones(N)
     dmass = np.zeros(N, dtype=np.float64)
+    dr = cfg.domain_rand
+    rsp = getattr(dr, "rigid_shape_properties", None)
+    shape_flags = [(k, bool(getattr(rsp, "randomize_" + k, False)), getattr(rsp, k + "_range", [0.0, 0.0]))
+                   for k in ("restitution", "compliance", "thickness")]
+    if any(f for _, f, _ in shape_flags) and num_shapes <= 0:
+        raise ValueError("rigid-shape randomisation needs the asset's shape count (model['num_shapes'])")
+    shape_props = np.zeros((N, max(num_shapes, 1), 3), dtype=np.float64)     # the asset defaults: 0
+    inv_mass = np.zeros(N, dtype=np.float64)
     start = origins.clone()                                # actor start position: env origin + U(-1, 1) in xy (:739-741)
     for i in range(N):
         start[i, :2] += (1.0 - (-1.0)) * torch.rand(2, 1).squeeze(1) + (-1.0)
@@ -50,13 +60,27 @@ def draw_env_constants(cfg, num_envs_total, body0_mass, terrain):
             bucket_ids = torch.randint(0, 64, (N, 1))
             buckets = (hi - lo) * torch.rand(64, 1) + lo
             friction = buckets[bucket_ids].reshape(N)
+        if cfg.domain_rand.randomize_friction:
+            for s in range(num_shapes):
+                for c, (_, on, rng) in enumerate(shape_flags):
+                    if on:
+                        shape_props[i, s, c] = np.random.uniform(rng[0], rng[1])
         if cfg.domain_rand.randomize_base_mass:
             lo, hi = cfg.domain_rand.added_mass_range
             dmass[i] = np.random.uniform(lo, hi)
+        if getattr(dr, "randomize_inv_base_mass", False):
+            lo, hi = dr.inv_mass_range
+            inv_mass[i] = np.random.uniform(lo, hi)
     out["start_pos"] = start
     out["friction"] = friction
     out["base_mass_delta"] = torch.from_numpy((body0_mass + dmass).astype(np.float32) - np.float32(body0_mass))
     out["base_mass"] = body0_mass + dmass
+    out["shape_props"], out["base_inv_mass"] = shape_props, inv_mass
+    # The sphere-set contact model carries one material per robot: the mean over the robot's shapes.
+    mat = np.zeros((N, 4), np.float32)
+    mat[:, :3] = shape_props.mean(1)
+    mat[:, 3] = inv_mass
+    out["material"] = torch.from_numpy(mat)
     return out
 
 
@@ -92,7 +116,7 @@ class LeggedRobot(BaseTask):
             setattr(self, name, getattr(s, name))
         self.num_dofs = self.num_dof
         body0_mass = float(self.robot_model["bodies"][0]["mass"])
-        consts = draw_env_constants(cfg, total, body0_mass, self.terrain)
+        consts = draw_env_constants(cfg, total, body0_mass, self.terrain, num_shapes=cm["num_shapes"])
         hs = self.terrain.heightsamples if self.terrain is not None else None
         self.core = HipEnvCore(s, hs, device=self.device)
         t = self.core.t
@@ -103,6 +127,9 @@ class LeggedRobot(BaseTask):
         t["root_states"][:, :3].copy_(consts["start_pos"][lo:hi])
         t["friction"].copy_(consts["friction"][lo:hi])
         t["base_mass_delta"].copy_(consts["base_mass_delta"][lo:hi])
+        t["material"].copy_(consts["material"][lo:hi])
+        self.rigid_shape_props = consts["shape_props"][lo:hi]          # (n, shapes, [restitution, compliance, thickness]) as drawn
+        self.base_inv_mass = consts["base_inv_mass"][lo:hi]
         self.fault_total, self.n_fault = t["fault_total"], t["n_fault"]
         if "terrain_levels" in consts:
             t["terrain_levels"].copy_(consts["terrain_levels"][lo:hi])
@@ -115,6 +142,37 @@ class LeggedRobot(BaseTask):
         self.common_step_counter = 0
         self.extras = {}
         self.init_done = True
+        self._curriculum_clock = CurriculumClock(s)
+        self.curriculum_state = 0
+        if s.use_curriculum:                                  # legged_robot.py:828-829 / legged_robot_trajectory.py:78-79
+            self.update_command_curriculum(in_callback=False)
+
+    # ------------------------------------------------------------------ staged curriculum
+    def update_command_curriculum(self, in_callback=True):
+        """legged_robot.py:488-505 / legged_robot_trajectory.py:519-553: the constants of ``curriculum_state`` into the device
+        (one lg_set_curriculum_stage call) and into the Python-side attributes the reference keeps.  in_callback: the change
+        belongs to the END of the next step's callback, as in the reference -- that step's own command resample / push /
+        generator resample still see the old stage (include/legged_hip.h lg_stage)."""
+        s = self.setup
+        v = s.stage_values(self.curriculum_state)
+        st = s.stage_struct(self.curriculum_state)
+        rc = self.core.lib.lg_set_curriculum_stage(self.core.ctx, C.byref(st), int(in_callback))
+        if rc != 0:
+            raise RuntimeError(f"lg_set_curriculum_stage failed ({rc}): {self.core.lib.lg_last_error().decode()}")
+        self.command_ranges, self.max_push_vel, self.push_time = v["command_ranges"], v["max_push_vel"], v["push_time"]
+        self.reward_scales = v["reward_scales"]
+        self._apply_stage_views(v)
+        print("----- Updated Curriculum -----")
+
+    def _apply_stage_views(self, v):
+        pass
+
+    def _curriculum_tick(self):
+        """The check at the end of _post_physics_step_callback (legged_robot.py:360-363), evaluated for the step about to run
+        (its common_step_counter is the current one + 1)."""
+        if self._curriculum_clock.tick(self.common_step_counter + 1):
+            self.curriculum_state = self._curriculum_clock.state
+            self.update_command_curriculum(in_callback=True)
 
     # ------------------------------------------------------------------ reward extension point
     def extra_reward_terms(self):
@@ -177,6 +235,7 @@ class LeggedRobot(BaseTask):
     # ------------------------------------------------------------------ VecEnv API
     def step(self, actions):
         a = actions.to(self.device, dtype=torch.float32).contiguous()
+        self._curriculum_tick()
         self.core.step(a)
         self.common_step_counter += 1
         self.extras["episode"] = self._extras_episode
@@ -201,6 +260,7 @@ class LeggedRobot(BaseTask):
             self.extras["time_outs"] = self._extras_time_outs
 
     def post_physics_step(self):
+        self._curriculum_tick()
         self.core.call("post_physics_step")
         self.common_step_counter += 1
 

@@ -74,6 +74,13 @@ class LeggedRobotTrajectory(LeggedRobot):
         t["tg_state"][:, off:off + 2].copy_(ramp[lo:lo + self.num_envs])
         t["push_timer"].copy_(timers[lo:lo + self.num_envs, 0])
 
+    def _apply_stage_views(self, v):
+        """The attributes update_command_curriculum rewrites (legged_robot_trajectory.py:530-550)."""
+        self.max_rom_distance = torch.tensor(v["max_rom_dist"], device=self.device)
+        self.rom.v_min, self.rom.v_max = torch.tensor(v["v_min"], device=self.device), torch.tensor(v["v_max"], device=self.device)
+        self.traj_gen.t_sampler = type("UniformSampleHoldDT", (), {"t_low": v["t_low"], "t_high": v["t_high"]})()
+        self.tracking_sigma = v["tracking_sigma"]
+
     def get_state(self):
         """(base pose 7, joint positions, base twist 6, joint velocities): the state vector dataset rollouts record
         (deep_tube_learning/data_collection_trajectory.py:25-26; HopperTrajectory.get_state hopper_trajectory.py:284)."""

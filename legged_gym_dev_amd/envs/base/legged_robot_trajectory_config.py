@@ -38,7 +38,21 @@ LeggedRobotTrajectoryCfg = cfg_class("LeggedRobotTrajectoryCfg", BaseConfig, dic
               soft_torque_limit=1.0, base_height_target=1.0, max_contact_force=100.0, tracking_sigma=0.25,
               differential_error=S(neg_slope=1.0, pos_slope=4.0),
               reward_weighting=S(position=1.0, velocity=1.0, orientation=0.3, angular_velocity=0.2, v_perp=0.4)),
-    curriculum=S(use_curriculum=False, curriculum_steps=[2500, 5000]),
+    # the authors' launch file (deep_tube_learning/configs/rl/default.yaml:77-109) switches this on with three stages; the two rows
+    # update_command_curriculum reads that no launch file of the ANYmal task defines (max_rom_distance,
+    # zero_rom_distance_likelihood: legged_robot_trajectory.py:530-531) are neutral here
+    curriculum=S(use_curriculum=False, curriculum_steps=[2500, 5000],
+                 push=S(magnitude=[0.1, 0.5, 1], time=[3, 2, 1]),
+                 max_rom_distance=[1.0, 1.0, 1.0], zero_rom_distance_likelihood=[1.0, 1.0, 1.0],
+                 trajectory_generator=S(weight_sampler=['UniformWeightSampler'] * 3, t_low=[3, 2, 1], t_high=[3, 2, 1],
+                                        freq_low=[0.01, 0.1, 1], freq_high=[0.1, 0.5, 1]),
+                 rom=S(z=[1, 1, 1], v=[0.5, 0.75, 1]),
+                 sigma=S(tracking_rom=[1.0, 0.8, 0.6]),
+                 rewards=S(**{k: [1.0, 0.8, 0.6] for k in (
+                     "tracking_rom", "feet_air_time", "stumble", "stand_still", "feet_contact_forces", "tracking_lin_vel",
+                     "tracking_ang_vel", "torque_limits", "dof_vel_limits", "dof_pos_limits", "termination", "collision",
+                     "action_rate", "dof_acc", "dof_vel", "torques", "base_height", "orientation", "ang_vel_xy", "lin_vel_z",
+                     "unit_quat", "differential_error")})),
     normalization=S(obs_scales=S(lin_vel=2.0, ang_vel=0.25, dof_pos=1.0, dof_vel=0.05, height_measurements=5.0, trajectory=[1.0, 1.0]),
                     clip_observations=100.0, clip_actions=100.0),
     noise=_B.noise,

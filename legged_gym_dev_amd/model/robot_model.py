@@ -137,4 +137,5 @@ def compile_model(model: dict) -> Dict[str, np.ndarray]:
         "sph_link": sph_link, "sph_body": sph_body,
         "sph_center": sph_center.astype(f32), "sph_radius": sph_radius.astype(f32),
         "body_names": list(model["body_names"]), "dof_names": list(model["dof_names"]),
+        "num_shapes": int(model.get("num_shapes", 0)),
     }

@@ -109,7 +109,8 @@ def load_urdf(path: str, collapse_fixed_joints: bool = True,
               replace_cylinder_with_capsule: bool = True) -> dict:
     root = ET.parse(path).getroot()
     links: Dict[str, _Link] = {}
-    for le in root.findall("link"):
+    num_shapes = 0                            # every <collision> geometry is one rigid shape of the asset (meshes: one convex hull
+    for le in root.findall("link"):           # each with vhacd off, legged_robot_config.py:104-124) -- len(rigid_shape_props)
         lk = _Link(le.get("name"))
         ine = le.find("inertial")
         if ine is not None:
@@ -123,6 +124,8 @@ def load_urdf(path: str, collapse_fixed_joints: bool = True,
                 lk.inertia = R @ I @ R.T
             lk.com = p
         for col in le.findall("collision"):
+            geom = col.find("geometry")
+            num_shapes += int(geom is not None and len(geom) > 0)
             s = _parse_shape(col)
             if s is not None:
                 lk.shapes.append(s)
@@ -231,7 +234,7 @@ def load_urdf(path: str, collapse_fixed_joints: bool = True,
                             spheres.append({"body": bi, "center": s["p"] + s["R"] @ c, "radius": rad})
 
     dof_names = [b["joint_name"] for b in bodies if b["joint_type"] == "revolute"]
-    return {"name": root.get("name", "robot"), "bodies": bodies, "spheres": spheres,
+    return {"name": root.get("name", "robot"), "bodies": bodies, "spheres": spheres, "num_shapes": num_shapes,
             "dof_names": dof_names, "body_names": [b["name"] for b in bodies]}
 
 

@@ -172,8 +172,9 @@ def _build_isaacgym_stub(state):
             return props
 
         def get_asset_rigid_shape_properties(self, a):
+            # one entry per rigid shape of the asset = per <collision> geometry of the URDF (model/urdf.py num_shapes)
             return [_Bag(friction=1.0, restitution=0.0, compliance=0.0, thickness=0.0)
-                    for _ in range(state["cm"]["num_spheres"])]
+                    for _ in range(state["cm"]["num_shapes"])]
 
         def get_asset_rigid_body_names(self, a):
             return list(state["cm"]["body_names"])
@@ -185,7 +186,7 @@ def _build_isaacgym_stub(state):
             return 0
 
         def set_asset_rigid_shape_properties(self, a, p):
-            pass
+            state.setdefault("shape_props", []).append([(float(s.restitution), float(s.compliance), float(s.thickness)) for s in p])
 
         def create_actor(self, env, asset, pose, name, i, sc, x):
             state.setdefault("start_xy", []).append((pose.p.x, pose.p.y))
@@ -199,6 +200,7 @@ def _build_isaacgym_stub(state):
 
         def set_actor_rigid_body_properties(self, e, a, props, recomputeInertia=True):
             state.setdefault("base_mass", []).append(props[0].mass)
+            state.setdefault("base_inv_mass", []).append(props[0].invMass)
 
         def find_actor_rigid_body_handle(self, e, a, name):
             return state["cm"]["body_names"].index(name)
@@ -389,7 +391,7 @@ def slot_layout(A, O):
     return s
 
 
-def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
+def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario, curriculum=None):
     N = cfg.env.num_envs
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -410,6 +412,15 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
     cfg.domain_rand.max_push_vel = cfg.domain_rand.max_push_vel_xy
     cfg.curriculum.use_curriculum = False
     cfg.curriculum.curriculum_steps = [100, 200]
+    if curriculum is not None:
+        # The staged command curriculum (legged_robot.py:360-363,488-505).  update_command_curriculum iterates over
+        # nominal_max_push_vel (:503), so max_push_vel has to be a list for _parse_cfg to get through -- and _push_robots then
+        # negates that list (:459) and raises: with the curriculum on the reference cannot push.  Pushes are off in this case.
+        cfg.curriculum.use_curriculum = True
+        cfg.curriculum.curriculum_steps = list(curriculum["steps"])
+        cfg.curriculum.commands = list(curriculum["commands"])
+        cfg.domain_rand.max_push_vel = [cfg.domain_rand.max_push_vel_xy]
+        cfg.domain_rand.push_robots = False
 
     sp = gymapi.SimParams()
     sp.dt = cfg.sim.dt
@@ -455,6 +466,9 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
         "friction_coeffs": env.friction_coeffs.numpy().reshape(-1) if hasattr(env, "friction_coeffs") else np.zeros(0),
         "base_mass": np.array(st.get("base_mass", []), dtype=np.float64),
         "start_xy": np.array(st.get("start_xy", []), dtype=np.float64),
+        # per env and rigid shape: restitution, compliance, thickness as handed to set_asset_rigid_shape_properties; inverse base mass
+        "shape_props": np.array(st.get("shape_props", []), dtype=np.float64),
+        "base_inv_mass": np.array(st.get("base_inv_mass", []), dtype=np.float64),
     }
     if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
         const["height_samples"] = env.height_samples.numpy().astype(np.int16)
@@ -466,7 +480,9 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
     meta = {"name": name, "robot": robot, "num_envs": N, "num_obs": O, "num_dofs": A, "num_bodies": B,
             "num_feet": F, "n_steps": n_steps, "reward_names": rew_names, "use_lstm": bool(use_lstm),
             "dt": float(env.dt), "max_episode_length": float(env.max_episode_length),
-            "push_time": float(env.push_time), "max_push_vel": float(env.max_push_vel),
+            "push_time": float(env.push_time),
+            "max_push_vel": float(env.max_push_vel[0] if isinstance(env.max_push_vel, list) else env.max_push_vel),
+            "use_curriculum": curriculum is not None, "curriculum_steps": list(cfg.curriculum.curriculum_steps),
             "resample_steps": int(cfg.commands.resampling_time / env.dt), "slots": S,
             "custom_origins": bool(env.custom_origins), "curriculum": bool(cfg.terrain.curriculum),
             "max_terrain_level": int(getattr(env, "max_terrain_level", 0)),
@@ -496,6 +512,8 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
     env.episode_length_buf[:6] = torch.tensor([rs - 1, 2 * rs - 1, rs - 2, int(env.max_episode_length),
                                                 int(env.max_episode_length) - 1, rs - 1])
     env.common_step_counter = int(env.push_time) - 3       # a push happens on the 3rd step
+    if curriculum is not None:
+        env.common_step_counter = int(curriculum["start_counter"])
     env.commands[:] = rnd(N, cfg.commands.num_commands)
     env.last_actions[:] = rnd(N, A)
     env.last_dof_vel[:] = rnd(N, A, lo=-3, hi=3)
@@ -534,8 +552,16 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
             d["lstm_c"] = env.sea_cell_state.numpy().copy()
         return d
 
+    def stage():
+        """What update_command_curriculum left in the env (legged_robot.py:488-505)."""
+        r = env.command_ranges
+        return {"curriculum_state": np.int64(env.curriculum_state), "stage_push_time": np.float64(env.push_time),
+                "stage_max_push_vel": np.float64(env.max_push_vel[0] if isinstance(env.max_push_vel, list) else env.max_push_vel),
+                "stage_command_ranges": np.array([r[k] for k in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")], np.float64)}
+
     init = snap()
     init["common_step_counter"] = np.int64(env.common_step_counter)
+    init.update(stage())
     for k, v in init.items():
         out[f"init_{k}"] = v
     for k, v in const.items():
@@ -634,6 +660,8 @@ def make_case(ref, name, robot, cfg, env_cls, n_steps, seed, scenario):
         out[p + "extras_episode"] = np.array([float(ep.get("rew_" + k, np.nan)) for k in rew_names], np.float64)
         out[p + "extras_terrain_level"] = np.float64(ep.get("terrain_level", np.nan))
         for k, v in snap().items():
+            out[p + "post_" + k] = v
+        for k, v in stage().items():
             out[p + "post_" + k] = v
         out[p + "n_reset"] = np.int64(int(dones.sum()))
     out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -736,6 +764,25 @@ def main():
     cfg.env.num_envs = 32
     small_terrain(cfg)
     make_case(ref, "anymal_b", "anymal_b", cfg, ref["Anymal"], 3, 18, "default")
+
+    # staged command curriculum of the base env (legged_robot.py:360-363,488-505): stage changes inside recorded steps 1 and 3
+    cfg = ref["AnymalCFlatCfg"]()
+    cfg.env.num_envs = 64
+    cfg.commands.ranges.lin_vel_x = [-1.0, 1.0]
+    cfg.commands.ranges.lin_vel_y = [-0.5, 1.5]
+    make_case(ref, "anymal_c_flat_curriculum", "anymal_c", cfg, ref["Anymal"], 5, 19, "default",
+              curriculum=dict(steps=[2252, 2254], commands=[0.5, 0.75, 1], start_counter=2250))
+
+    # every randomisation of the property callbacks on (legged_robot.py:259-341): the numpy stream is shared by the per-shape
+    # restitution / compliance / thickness draws, the base mass and the inverse base mass, in that order per env
+    cfg = ref["AnymalCFlatCfg"]()
+    cfg.env.num_envs = 32
+    cfg.domain_rand.randomize_base_mass = True
+    cfg.domain_rand.added_mass_range = [-5.0, 5.0]
+    cfg.domain_rand.randomize_inv_base_mass = True
+    rsp = cfg.domain_rand.rigid_shape_properties
+    rsp.randomize_restitution = rsp.randomize_compliance = rsp.randomize_thickness = True
+    make_case(ref, "anymal_c_randomised", "anymal_c", cfg, ref["Anymal"], 2, 20, "default")
 
     lstm_fixture()
 

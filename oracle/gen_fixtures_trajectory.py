@@ -21,6 +21,13 @@ the missing attributes):
   * cfg.curriculum is read (:78,414) but not defined                 -> use_curriculum = False
   * rewards.tracking_sigma is read (:892) but not defined            -> 0.25 (hopper_single_int.yaml:29, LeggedRobotCfg's value)
   * domain_rand.rigid_shape_properties.* / randomize_inv_base_mass are read (:349-359,392) but not defined -> all False
+  * the rough-terrain task (anymal_c_rough_trajectory): env.num_observations is 240 in the base class (:38, a 4-point window) but
+    compute_observations builds 252 columns with N = 10 (:280-295)   -> 252; terrain.slope_treshold is read by utils/terrain.py:73
+    but the trajectory config spells it slope_threshold (:66)         -> alias
+    ; with terrain.curriculum = True (its default) the first reset raises: _update_terrain_curriculum reads self.commands (:508),
+    which the trajectory env never creates                            -> terrain.curriculum = False
+  * the staged curriculum reads curriculum.max_rom_distance / zero_rom_distance_likelihood (:530-531), rows no launch file of the
+    ANYmal task has                                                   -> given here (CURRICULUM below)
   * UniformWeightSampler draws with device='cuda' hard-coded (deep_tube_learning/utils.py:52) -> the recorder drops the
     device argument (CPU run)
 The reward table of the fork's flat trajectory config has no tracking term at all; the fixture enables the authors' table
@@ -96,10 +103,27 @@ def load_trajectory_modules():
               "legged_gym/envs/anymal_c/flat_trajectory/anymal_c_flat_trajectory_config.py")
     at = load("legged_gym.envs.anymal_c.anymal_trajectory", "legged_gym/envs/anymal_c/anymal_trajectory.py")
     return {"AnymalTrajectory": at.AnymalTrajectory, "AnymalCFlatTrajectoryCfg": ft.AnymalCFlatTrajectoryCfg,
-            "LeggedRobotTrajectory": lrt.LeggedRobotTrajectory}
+            "AnymalCRoughTrajectoryCfg": rt.AnymalCRoughTrajectoryCfg, "LeggedRobotTrajectory": lrt.LeggedRobotTrajectory}
 
 
-def patch_cfg(cfg, use_lstm=True):
+CURRICULUM = dict(   # the authors' launch file (deep_tube_learning/configs/rl/default.yaml:77-109) in small: stage changes at steps 2 and 4
+    use_curriculum=True, curriculum_steps=[2, 4],
+    push=dict(magnitude=[0.1, 0.5, 1], time=[3, 2, 1]),
+    # read by update_command_curriculum (legged_robot_trajectory.py:530-531) but in no launch file of the ANYmal task
+    max_rom_distance=[0.5, 0.75, 1.0], zero_rom_distance_likelihood=[1.0, 2.0, 3.0],
+    trajectory_generator=dict(weight_sampler=['UniformWeightSampler'] * 3, t_low=[3, 2, 1], t_high=[3, 2, 1],
+                              freq_low=[0.01, 0.1, 1], freq_high=[0.1, 0.5, 1]),
+    rom=dict(z=[1, 1, 1], v=[0.5, 0.75, 1]),
+    sigma=dict(tracking_rom=[1.0, 0.8, 0.6]),
+    rewards={k: [1.0, 0.8, 0.6] for k in ("tracking_rom", "feet_air_time", "termination", "collision", "action_rate", "dof_acc",
+                                           "torques", "orientation", "ang_vel_xy", "differential_error")})
+
+
+def _ns(d):
+    return types.SimpleNamespace(**{k: _ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def patch_cfg(cfg, use_lstm=True, curriculum=False):
     """The repairs listed in the module docstring + the authors' reward table."""
     tg = cfg.trajectory_generator
     tg.weight_samp_cls = "UniformWeightSampler"
@@ -111,7 +135,7 @@ def patch_cfg(cfg, use_lstm=True):
     dr.zero_rom_distance_likelihood = 0.25
     dr.rigid_shape_properties = types.SimpleNamespace(randomize_restitution=False, randomize_compliance=False, randomize_thickness=False)
     dr.randomize_inv_base_mass = False
-    cfg.curriculum = types.SimpleNamespace(use_curriculum=False, curriculum_steps=[2500, 5000])
+    cfg.curriculum = _ns(CURRICULUM) if curriculum else types.SimpleNamespace(use_curriculum=False, curriculum_steps=[2500, 5000])
     cfg.control.use_actuator_network = use_lstm
     sc = cfg.rewards.scales
     for k, v in dict(termination=-0.5, tracking_rom=6.0, differential_error=-1.5, ang_vel_xy=-0.05, orientation=-1.0,
@@ -138,9 +162,21 @@ class TrajDrawLog(gf._DrawLog):
         return f
 
 
-def make_traj_case(mods, name, n_steps, seed):
-    cfg = patch_cfg(mods["AnymalCFlatTrajectoryCfg"]())
+def make_traj_case(mods, name, n_steps, seed, cfg_name="AnymalCFlatTrajectoryCfg", curriculum=False):
+    cfg = patch_cfg(mods[cfg_name](), curriculum=curriculum)
     N = cfg.env.num_envs = 64
+    rough = cfg.terrain.mesh_type in ("heightfield", "trimesh")
+    if rough:
+        gf.small_terrain(cfg)
+        # the base class says 240 (legged_robot_trajectory_config.py:38: a 4-point window); compute_observations builds
+        # 9 + 2 N + 36 + 187 = 252 columns with the committed N = 10 and its noise line fails on the mismatch (:280-295)
+        cfg.env.num_observations = 252
+        # the trajectory config spells terrain.slope_threshold (:66), utils/terrain.py:73 reads slope_treshold as in the base config
+        if not hasattr(cfg.terrain, "slope_treshold"):
+            cfg.terrain.slope_treshold = cfg.terrain.slope_threshold
+        # _update_terrain_curriculum reads self.commands (:508), which this env never creates: with terrain.curriculum on (the
+        # registered default) the first reset raises AttributeError.  The terrain curriculum is therefore off in this fixture.
+        cfg.terrain.curriculum = False
     robot = "anymal_c"
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -231,8 +267,20 @@ def make_traj_case(mods, name, n_steps, seed):
              "time_until_next_push": env.time_until_next_push.numpy().copy().reshape(N),
              "trajectory": env.trajectory.numpy().copy(),
              "lstm_h": env.sea_hidden_state.numpy().copy(), "lstm_c": env.sea_cell_state.numpy().copy()}
+        if rough:
+            d["terrain_levels"] = env.terrain_levels.numpy().copy()
         d.update(tg_state())
         return d
+
+    def stage():
+        """What update_command_curriculum left in the env (legged_robot_trajectory.py:519-553)."""
+        return {"curriculum_state": np.int64(env.curriculum_state),
+                "stage_reward_scales": np.array([env.reward_scales[k] for k in rew_names], np.float64),
+                "stage_tracking_sigma": np.float64(env.tracking_sigma),
+                "stage_v_min": env.rom.v_min.numpy().copy(), "stage_v_max": env.rom.v_max.numpy().copy(),
+                "stage_t_low": np.float64(tgen.t_sampler.t_low), "stage_t_high": np.float64(tgen.t_sampler.t_high),
+                "stage_max_rom_distance": env.max_rom_distance.numpy().copy(),
+                "stage_zero_rom_dist_llh": np.float64(env.zero_rom_dist_llh)}
 
     # ---- a plausible mid-episode state: run the generator's own reset for everyone (its draws are not part of the fixture),
     # then scatter the clocks so that resamples, ROM steps and pushes fall inside the recorded steps
@@ -281,6 +329,11 @@ def make_traj_case(mods, name, n_steps, seed):
         "reward_weighting": env.reward_weighting.numpy(), "trajectory_scale": env.trajectory_scale.numpy(),
         "rom_v_min": env.rom.v_min.numpy(), "rom_v_max": env.rom.v_max.numpy(),
         "max_rom_distance": env.max_rom_distance.numpy()}
+    if rough:
+        const.update(height_samples=env.height_samples.numpy().astype(np.int16), terrain_origins=env.terrain_origins.numpy(),
+                     terrain_levels_init=env.terrain_levels.numpy().copy(), terrain_types=env.terrain_types.numpy(),
+                     height_points=env.height_points[0].numpy(), friction_coeffs=env.friction_coeffs.numpy().reshape(-1),
+                     base_mass=np.array(st.get("base_mass", []), dtype=np.float64))
     meta = {"name": name, "robot": robot, "num_envs": N, "num_obs": O, "num_dofs": A, "num_bodies": B, "num_feet": F,
             "n_steps": n_steps, "reward_names": rew_names, "use_lstm": True, "dt": float(env.dt),
             "max_episode_length": float(env.max_episode_length), "slots": S, "custom_origins": bool(env.custom_origins),
@@ -291,8 +344,12 @@ def make_traj_case(mods, name, n_steps, seed):
             "time_between_pushes": [float(v) for v in cfg.domain_rand.time_between_pushes],
             "t_low": float(tgen.t_sampler.t_low), "t_high": float(tgen.t_sampler.t_high), "freq_low": float(tgen.freq_low),
             "freq_high": float(tgen.freq_high), "prob_stationary": float(tgen.prob_stationary),
-            "neg_slope": float(cfg.rewards.differential_error.neg_slope), "pos_slope": float(cfg.rewards.differential_error.pos_slope)}
+            "neg_slope": float(cfg.rewards.differential_error.neg_slope), "pos_slope": float(cfg.rewards.differential_error.pos_slope),
+            "use_curriculum": bool(curriculum), "curriculum_steps": list(cfg.curriculum.curriculum_steps),
+            "max_terrain_level": int(getattr(env, "max_terrain_level", 0)),
+            "terrain_env_length": float(getattr(getattr(env, "terrain", None), "env_length", 0.0) or 0.0)}
     init = snap()
+    init.update(stage())
     init["common_step_counter"] = np.int64(env.common_step_counter)
     for k, v in init.items():
         out[f"init_{k}"] = v
@@ -336,6 +393,7 @@ def make_traj_case(mods, name, n_steps, seed):
 
         # ---- lay the recorded draws out per env
         U = np.full((N, S["K"]), np.nan, dtype=np.float32)
+        lvl = np.full((N,), -1, dtype=np.int64)
         cnt = {}
         n_tg = 0
         for tag, ids, ten in log.entries:
@@ -357,8 +415,13 @@ def make_traj_case(mods, name, n_steps, seed):
                 U[np.nonzero(env_push_mask)[0], S["timer"]] = v.reshape(-1)
             elif tag == "reset_dof":
                 U[ii, S["dof"]:S["dof"] + A] = v
+            elif tag == "curric":
+                lvl[ii] = ten.numpy()
             elif tag == "reset_root":
-                U[ii, S["vel"]:S["vel"] + 6] = v
+                if env.custom_origins and k == 0:
+                    U[ii, S["xy"]:S["xy"] + 2] = v
+                else:
+                    U[ii, S["vel"]:S["vel"] + 6] = v
             elif tag == "romd":
                 if k == 0:
                     U[ii, S["romd"]] = v.reshape(-1)
@@ -375,6 +438,10 @@ def make_traj_case(mods, name, n_steps, seed):
         out[p + "new_root"] = new_root.numpy()
         out[p + "contact_forces"] = cf.numpy()
         out[p + "uniforms"] = U
+        out[p + "inj_level"] = lvl
+        out[p + "measured_heights"] = (env.measured_heights.numpy().copy() if torch.is_tensor(env.measured_heights)
+                                       else np.zeros((N, 0), np.float32))
+        out[p + "extras_terrain_level"] = np.float64(infos.get("episode", {}).get("terrain_level", np.nan))
         out[p + "obs"] = obs.numpy().copy()
         out[p + "rew"] = rew.numpy().copy()
         out[p + "reset"] = dones.numpy().copy()
@@ -384,6 +451,8 @@ def make_traj_case(mods, name, n_steps, seed):
         ep = infos.get("episode", {})
         out[p + "extras_episode"] = np.array([float(ep.get("rew_" + k, np.nan)) for k in rew_names], np.float64)
         for k, v in snap().items():
+            out[p + "post_" + k] = v
+        for k, v in stage().items():
             out[p + "post_" + k] = v
         out[p + "n_reset"] = np.int64(int(dones.sum()))
         out[p + "n_pushed"] = np.int64(int(env_push_mask.sum()))
@@ -422,6 +491,10 @@ def main():
     cls._push_robots = push_spy
     cls.post_physics_step = pps_spy
     make_traj_case(mods, "anymal_c_flat_trajectory", 6, 21)
+    # the staged curriculum the authors train with (default.yaml:77-109): stage changes fall on recorded steps 1 and 3
+    make_traj_case(mods, "anymal_c_flat_trajectory_curriculum", 6, 22, curriculum=True)
+    # the registered rough-terrain task (legged_gym/envs/__init__.py:55-56): height scan + terrain curriculum + 252 observations
+    make_traj_case(mods, "anymal_c_rough_trajectory", 5, 23, cfg_name="AnymalCRoughTrajectoryCfg")
 
 
 if __name__ == "__main__":

@@ -31,6 +31,18 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
         e->terrain_origins.assign(cfg->terrain_origins,
                                   cfg->terrain_origins + (size_t)cfg->max_terrain_level * cfg->terrain_num_cols * 3);
     e->cfg.noise_vec = e->cfg.height_points = e->cfg.terrain_origins = nullptr;
+    {   // the stage in force = what the cfg holds
+        lg_stage s;
+        std::memset(&s, 0, sizeof(s));
+        std::memcpy(s.cmd_lo, cfg->cmd_lo, sizeof(s.cmd_lo)); std::memcpy(s.cmd_hi, cfg->cmd_hi, sizeof(s.cmd_hi));
+        s.max_push_vel = cfg->max_push_vel; s.push_time = (double)cfg->push_interval;
+        std::memcpy(s.rew_scale, cfg->rew_scale, sizeof(s.rew_scale));
+        for (int k = 0; k < LG_MAX_XTERMS; ++k) { s.xterm_scale[k] = cfg->xterms[k].scale; s.xterm_p0[k] = cfg->xterms[k].p[0]; }
+        std::memcpy(s.traj_v_min, cfg->traj.v_min, 8); std::memcpy(s.traj_v_max, cfg->traj.v_max, 8);
+        s.traj_t_low = cfg->traj.t_low; s.traj_t_high = cfg->traj.t_high;
+        std::memcpy(s.traj_max_rom_dist, cfg->traj.max_rom_dist, 8);
+        stage_apply(*e, s, 3);
+    }
     auto z = [](std::vector<float> &v, size_t n) { v.assign(n, 0.0f); };
     z(e->root, (size_t)N * 13); z(e->dof, (size_t)N * A * 2); z(e->contact, (size_t)N * B * 3);
     z(e->torques, (size_t)N * A); z(e->actions, (size_t)N * A); z(e->obs, (size_t)N * O); z(e->rew, N);
@@ -39,7 +51,7 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
     z(e->episode_sums, (size_t)LG_NUM_TERMS * N); z(e->base_lin_vel, (size_t)N * 3);
     z(e->base_ang_vel, (size_t)N * 3); z(e->proj_grav, (size_t)N * 3); z(e->heights, (size_t)N * (H ? H : 1));
     z(e->env_origins, (size_t)N * 3); z(e->lstm_h, (size_t)2 * N * A * 8); z(e->lstm_c, (size_t)2 * N * A * 8);
-    z(e->friction, N); z(e->base_mass_delta, N); z(e->extras_episode, LG_NUM_TERMS);
+    z(e->friction, N); z(e->base_mass_delta, N); z(e->extras_episode, LG_NUM_TERMS); z(e->material, (size_t)N * 4);
     z(e->extras_terrain_level, 1); z(e->extras_episode_acc, LG_NUM_TERMS + 2);
     {
         const int npts = cfg->traj.enabled ? cfg->traj.N * cfg->traj.dN + 1 : 1, nobs = cfg->traj.enabled ? cfg->traj.N : 1;
@@ -75,7 +87,7 @@ int lgo_get_buffers(void *ctx, lg_buffers *b) {
     b->extras_episode_acc = e->extras_episode_acc.data(); b->n_fault = e->n_fault.data(); b->fault_total = e->fault_total.data();
     b->tg_state = e->tg_state.data(); b->tg_traj = e->tg_traj.data(); b->trajectory = e->trajectory.data();
     b->prev_error = e->prev_error.data(); b->push_timer = e->push_timer.data();
-    b->inject_uniforms = e->inj_u.data(); b->inject_levels = e->inj_levels.data();
+    b->inject_uniforms = e->inj_u.data(); b->inject_levels = e->inj_levels.data(); b->material = e->material.data();
     return 0;
 }
 
@@ -83,6 +95,15 @@ int lgo_set_step_counter(void *ctx, int64_t c) { ((Env *)ctx)->step_counter = c;
 int64_t lgo_get_step_counter(void *ctx) { return ((Env *)ctx)->step_counter; }
 int lgo_set_init_done(void *ctx, int v) { ((Env *)ctx)->init_done = v; return 0; }
 int lgo_inject_uniforms(void *ctx, int enable) { ((Env *)ctx)->inject = enable; return 0; }
+
+int lgo_get_stage(void *ctx, lg_stage *out) { Env *e = (Env *)ctx; *out = e->has_pending ? e->pending : e->stage; return 0; }
+int lgo_set_curriculum_stage(void *ctx, const lg_stage *s, int in_callback) {
+    Env *e = (Env *)ctx;
+    if (in_callback) { e->pending = *s; e->has_pending = 1; return 0; }
+    e->has_pending = 0;
+    stage_apply(*e, *s, 3);
+    return 0;
+}
 
 int lgo_set_actions(void *ctx, const float *actions) {                 // legged_robot.py:86-87
     Env *e = (Env *)ctx;

@@ -52,8 +52,14 @@ struct Env {
     std::vector<int64_t> ep_len, terrain_levels, terrain_types, inj_levels;
     std::vector<int32_t> n_reset, n_fault;
     std::vector<int64_t> fault_total;
+    std::vector<float> material;                 // (N, 4): restitution, compliance, thickness, inverse base mass
     int64_t step_counter = 0;
     int init_done = 1, inject = 0;
+    // staged curriculum (legged_hip.h lg_stage): cfg holds what is read AFTER the step callback; cb what the callback itself
+    // reads (command resample, push, generator resample: LR:343-363, LT:405-417 change the stage at the callback's end)
+    lg_stage stage, pending;
+    int has_pending = 0;
+    struct { float cmd_lo[4], cmd_hi[4], max_push_vel; lg_traj_cfg traj; } cb;
 };
 
 void compute_torques(Env &e);
@@ -63,7 +69,8 @@ void reset_all(Env &e);
 void reset_ids(Env &e, const int32_t *ids, int n);
 // trajectory env (lgo_traj.cpp)
 float uni(const Env &e, int env, int slot);
-void tg_callback_step(Env &e, int i);
+void tg_callback_step(Env &e, int i);           // resamples with e.cb.traj
+void stage_apply(Env &e, const lg_stage &s, int what);   // what & 1: cfg, what & 2: cb
 void tg_reset(Env &e, int i, const float z[2]);
 void tg_late_resample(Env &e, int i);
 

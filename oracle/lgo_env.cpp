@@ -33,15 +33,15 @@ static inline float clampf(float x, float lo, float hi) { return std::min(std::m
 
 
 // LR:365-387
-static void resample_commands(Env &e, int i, int slot0) {
+static void resample_commands(Env &e, int i, int slot0, const float *lo, const float *hi) {
     const lg_cfg &c = e.cfg;
     float *cmd = &e.commands[(size_t)i * 4];
-    cmd[0] = (c.cmd_hi[0] - c.cmd_lo[0]) * uni(e, i, slot0 + 0) + c.cmd_lo[0];
-    cmd[1] = (c.cmd_hi[1] - c.cmd_lo[1]) * uni(e, i, slot0 + 1) + c.cmd_lo[1];
+    cmd[0] = (hi[0] - lo[0]) * uni(e, i, slot0 + 0) + lo[0];
+    cmd[1] = (hi[1] - lo[1]) * uni(e, i, slot0 + 1) + lo[1];
     if (c.heading_command)
-        cmd[3] = (c.cmd_hi[3] - c.cmd_lo[3]) * uni(e, i, slot0 + 2) + c.cmd_lo[3];
+        cmd[3] = (hi[3] - lo[3]) * uni(e, i, slot0 + 2) + lo[3];
     else
-        cmd[2] = (c.cmd_hi[2] - c.cmd_lo[2]) * uni(e, i, slot0 + 2) + c.cmd_lo[2];
+        cmd[2] = (hi[2] - lo[2]) * uni(e, i, slot0 + 2) + lo[2];
     float nrm = std::sqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1]);
     float keep = nrm > 0.2f ? 1.0f : 0.0f;
     cmd[0] *= keep;
@@ -268,7 +268,7 @@ static void reset_env(Env &e, int i) {
             e.prev_error[(size_t)i * 2 + k] = d * d;
         }
     } else {
-        resample_commands(e, i, LG_SLOT_RCMD(A));
+        resample_commands(e, i, LG_SLOT_RCMD(A), c.cmd_lo, c.cmd_hi);
     }
     for (int j = 0; j < A; ++j) { e.last_actions[(size_t)i * A + j] = 0.0f; e.last_dof_vel[(size_t)i * A + j] = 0.0f; }
     for (int f = 0; f < e.F; ++f) e.feet_air_time[(size_t)i * e.F + f] = 0.0f;
@@ -284,12 +284,36 @@ static void reset_env(Env &e, int i) {
                 }
 }
 
+// LR:488-505 / LT:519-553 as data (legged_hip.h lg_stage)
+void stage_apply(Env &e, const lg_stage &s, int what) {
+    lg_cfg &c = e.cfg;
+    if (what & 1) {
+        for (int k = 0; k < 4; ++k) { c.cmd_lo[k] = s.cmd_lo[k]; c.cmd_hi[k] = s.cmd_hi[k]; }
+        c.max_push_vel = s.max_push_vel;
+        for (int k = 0; k < LG_NUM_REWARDS; ++k) c.rew_scale[k] = s.rew_scale[k];
+        for (int k = 0; k < LG_MAX_XTERMS; ++k) { c.xterms[k].scale = s.xterm_scale[k]; c.xterms[k].p[0] = s.xterm_p0[k]; }
+        for (int k = 0; k < 2; ++k) { c.traj.v_min[k] = s.traj_v_min[k]; c.traj.v_max[k] = s.traj_v_max[k]; c.traj.max_rom_dist[k] = s.traj_max_rom_dist[k]; }
+        c.traj.t_low = s.traj_t_low; c.traj.t_high = s.traj_t_high;
+    }
+    if (what & 2) {
+        for (int k = 0; k < 4; ++k) { e.cb.cmd_lo[k] = s.cmd_lo[k]; e.cb.cmd_hi[k] = s.cmd_hi[k]; }
+        e.cb.max_push_vel = s.max_push_vel;
+        e.cb.traj = c.traj;
+        for (int k = 0; k < 2; ++k) { e.cb.traj.v_min[k] = s.traj_v_min[k]; e.cb.traj.v_max[k] = s.traj_v_max[k]; }
+        e.cb.traj.t_low = s.traj_t_low; e.cb.traj.t_high = s.traj_t_high;
+        e.stage = s;
+    }
+}
+
 // LR:106-137 followed by the obs clip of LR:100-103
 void post_physics_step(Env &e) {
     const lg_cfg &c = e.cfg;
     const int N = e.N, A = e.A, B = e.B, O = e.O;
     e.step_counter += 1;                                              // LR:115
-    const bool push_now = c.push_robots && c.push_interval > 0 && (e.step_counter % c.push_interval == 0);
+    // LR:358 on the push period of the stage in force when the step began (fractional after a curriculum multiplier)
+    const double pt = e.stage.push_time;
+    const bool push_now = c.push_robots && pt > 0.0 && std::fmod((double)e.step_counter, pt) == 0.0;
+    if (e.has_pending) stage_apply(e, e.pending, 1);                  // LR:360-363 / LT:414-417: what follows the callback sees the new stage
     std::vector<uint8_t> was_reset(N, 0), was_fault(N, 0);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < N; ++i) {
@@ -304,7 +328,7 @@ void post_physics_step(Env &e) {
         quat_rotate_inverse(r + 3, gvec, pg);
         // ---- _post_physics_step_callback LR:343-363 / LT:405-417
         if (c.traj.enabled) tg_callback_step(e, i);
-        else if (e.ep_len[i] % c.resample_steps == 0) resample_commands(e, i, LG_SLOT_CMD);
+        else if (e.ep_len[i] % c.resample_steps == 0) resample_commands(e, i, LG_SLOT_CMD, e.cb.cmd_lo, e.cb.cmd_hi);
         if (c.heading_command && !c.traj.enabled) {
             const float fwd0[3] = {1.0f, 0.0f, 0.0f};
             float fwd[3];
@@ -327,8 +351,9 @@ void post_physics_step(Env &e) {
                 e.push_timer[i] = (c.traj.push_t_hi - c.traj.push_t_lo) * uni(e, i, LG_TSLOT_TIMER) + c.traj.push_t_lo;
             }
         } else if (push_now) {                                        // LR:456-461
-            r[7] = (c.max_push_vel - (-c.max_push_vel)) * uni(e, i, LG_SLOT_PUSH) + (-c.max_push_vel);
-            r[8] = (c.max_push_vel - (-c.max_push_vel)) * uni(e, i, LG_SLOT_PUSH + 1) + (-c.max_push_vel);
+            const float mv = e.cb.max_push_vel;
+            r[7] = (mv - (-mv)) * uni(e, i, LG_SLOT_PUSH) + (-mv);
+            r[8] = (mv - (-mv)) * uni(e, i, LG_SLOT_PUSH + 1) + (-mv);
         }
         // ---- check_termination LR:139-145
         bool rst = false;
@@ -437,6 +462,7 @@ void post_physics_step(Env &e) {
         }
         for (int k = 0; k < 6; ++k) e.last_root_vel[(size_t)i * 6 + k] = r[7 + k];
     }
+    if (e.has_pending) { stage_apply(e, e.pending, 2); e.has_pending = 0; }   // from the next step on the callback sees it too
 }
 
 // base_task.py:113 reset_idx(arange(N)) -- no extras bookkeeping needed by callers

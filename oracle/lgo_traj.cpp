@@ -15,8 +15,7 @@ float uni(const Env &e, int env, int slot) {
 
 // RD:507-515: redraw every input law, the hold time, the mixing weights and the stationary flag of env i.
 // uniform(low, high) = (high - low) * rand + low (RD:478-479)
-static void tg_resample(Env &e, int i, int slot0) {
-    const lg_traj_cfg &t = e.cfg.traj;
+static void tg_resample(Env &e, const lg_traj_cfg &t, int i, int slot0) {
     float *s = &e.tg_state[(size_t)i * LG_TG_STRIDE];
     const float pi = 3.14159265358979323846f;
     for (int d = 0; d < 2; ++d)                                             // _resample_const_input RD:523-524
@@ -95,7 +94,7 @@ void tg_callback_step(Env &e, int i) {
     const lg_traj_cfg &t = e.cfg.traj;
     float *s = &e.tg_state[(size_t)i * LG_TG_STRIDE];
     const float tt = s[LG_TG_T];
-    if (tt > s[LG_TG_T_FINAL]) tg_resample(e, i, LG_TSLOT_TG);             // get_input_t RD:560-561 (every env, every step)
+    if (tt > s[LG_TG_T_FINAL]) tg_resample(e, e.cb.traj, i, LG_TSLOT_TG);  // get_input_t RD:560-561 (every env, every step)
     float v[2];
     tg_input(e, i, tt, v);
     tg_keep_v(e, i, v);
@@ -115,7 +114,7 @@ void tg_reset(Env &e, int i, const float z0[2]) {
     s[LG_TG_K] = -(float)(t.N * t.dN);
     s[LG_TG_T] = s[LG_TG_K] * t.rom_dt;
     s[LG_TG_T_FINAL] = s[LG_TG_K] * t.rom_dt;
-    tg_resample(e, i, LG_TSLOT_RTG(A));
+    tg_resample(e, e.cfg.traj, i, LG_TSLOT_RTG(A));
     for (int it = 0; it < t.N * t.dN; ++it) {                               // step_rom_idx(idx, increment_rom_time=True)
         float v[2];
         tg_input(e, i, s[LG_TG_T], v);
@@ -129,7 +128,7 @@ void tg_reset(Env &e, int i, const float z0[2]) {
 // did not reset but whose hold time ran out after the callback's time increment is resampled there.
 void tg_late_resample(Env &e, int i) {
     const float *s = &e.tg_state[(size_t)i * LG_TG_STRIDE];
-    if (s[LG_TG_T] > s[LG_TG_T_FINAL]) tg_resample(e, i, LG_TSLOT_RTG(e.A));
+    if (s[LG_TG_T] > s[LG_TG_T_FINAL]) tg_resample(e, e.cfg.traj, i, LG_TSLOT_RTG(e.A));
     float v[2];                                                              // and leaves self.v evaluated at the env's new time
     tg_input(e, i, s[LG_TG_T], v);
     tg_keep_v(e, i, v);

@@ -17,7 +17,8 @@ from legged_gym_dev_amd.envs.base.env_setup import EnvSetup, sim_dt_float  # noq
 from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FIXTURES = ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_allrewards", "anymal_c_pd_V", "anymal_c_pd_T", "a1", "anymal_b"]
+FIXTURES = ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_allrewards", "anymal_c_pd_V", "anymal_c_pd_T", "a1", "anymal_b",
+            "anymal_c_flat_curriculum", "anymal_c_randomised"]
 
 
 def load_fixture(name):
@@ -39,6 +40,20 @@ def make_cfg(name):
     if name == "anymal_c_flat":
         cfg = AnymalCFlatCfg()
         cfg.env.num_envs = 64
+    elif name == "anymal_c_flat_curriculum":              # staged command curriculum, stage changes inside recorded steps 1 and 3
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 64
+        cfg.commands.ranges.lin_vel_x, cfg.commands.ranges.lin_vel_y = [-1.0, 1.0], [-0.5, 1.5]
+        cfg.curriculum.use_curriculum, cfg.curriculum.curriculum_steps, cfg.curriculum.commands = True, [2252, 2254], [0.5, 0.75, 1]
+        cfg.domain_rand.max_push_vel = [cfg.domain_rand.max_push_vel_xy]      # the list form the reference's curriculum needs
+        cfg.domain_rand.push_robots = False                                    # (and with which its _push_robots raises)
+    elif name == "anymal_c_randomised":                   # every randomisation of the property callbacks on
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 32
+        cfg.domain_rand.randomize_base_mass, cfg.domain_rand.added_mass_range = True, [-5.0, 5.0]
+        cfg.domain_rand.randomize_inv_base_mass = True
+        rsp = cfg.domain_rand.rigid_shape_properties
+        rsp.randomize_restitution = rsp.randomize_compliance = rsp.randomize_thickness = True
     elif name == "anymal_c_rough":
         cfg = AnymalCRoughCfg()
         cfg.env.num_envs = 64
@@ -76,11 +91,21 @@ def make_cfg(name):
         cfg = AnymalBRoughCfg()
         cfg.env.num_envs = 32
         _small_terrain(cfg)
-    elif name == "anymal_c_flat_trajectory":
+    elif name in ("anymal_c_flat_trajectory", "anymal_c_flat_trajectory_curriculum", "anymal_c_rough_trajectory"):
         # the repairs + reward table of oracle/gen_fixtures_trajectory.py::patch_cfg, on this repo's config class
-        from legged_gym_dev_amd.envs.anymal_c.flat_trajectory.anymal_c_flat_trajectory_config import AnymalCFlatTrajectoryCfg
-        cfg = AnymalCFlatTrajectoryCfg()
+        if name == "anymal_c_rough_trajectory":
+            from legged_gym_dev_amd.envs.anymal_c.mixed_terrains_trajectory.anymal_c_rough_trajectory_config import AnymalCRoughTrajectoryCfg
+            cfg = AnymalCRoughTrajectoryCfg()
+            _small_terrain(cfg)
+            cfg.terrain.curriculum = False          # with it on the reference's first reset raises (gen_fixtures_trajectory.py)
+        else:
+            from legged_gym_dev_amd.envs.anymal_c.flat_trajectory.anymal_c_flat_trajectory_config import AnymalCFlatTrajectoryCfg
+            cfg = AnymalCFlatTrajectoryCfg()
         cfg.env.num_envs = 64
+        if name.endswith("_curriculum"):            # gen_fixtures_trajectory.py::CURRICULUM (the other rows are the config's own)
+            cur = cfg.curriculum
+            cur.use_curriculum, cur.curriculum_steps = True, [2, 4]
+            cur.max_rom_distance, cur.zero_rom_distance_likelihood = [0.5, 0.75, 1.0], [1.0, 2.0, 3.0]
         cfg.domain_rand.randomize_rom_distance = True
         cfg.domain_rand.max_rom_dist = [0.3, 0.2]
         cfg.domain_rand.zero_rom_distance_likelihood = 0.25
@@ -141,25 +166,29 @@ def check_setup_against_fixture(setup, z, meta):
                                   z["const_reward_scales"])
     assert setup.dt == meta["dt"]
     assert setup.max_episode_length == meta["max_episode_length"]
-    if "push_time" in meta:
-        assert setup.push_time == meta["push_time"]
+    if "push_time" in meta:          # (with the staged curriculum on, _parse_cfg has already applied stage 0: legged_robot.py:828-829)
+        sv0 = setup.stage_values(0 if setup.use_curriculum else None)
+        assert sv0["push_time"] == meta["push_time"] and sv0["max_push_vel"] == meta["max_push_vel"]
+        assert setup.use_curriculum == bool(meta.get("use_curriculum", False))
     if "resample_steps" in meta:
         assert int(setup.cfg.commands.resampling_time / setup.dt) == meta["resample_steps"]
     if setup.measure_heights:
         np.testing.assert_array_equal(setup.height_points, z["const_height_points"][:, :2])
     if setup.traj is not None:                              # what _init_rom / _init_trajectory_generator / _init_buffers derived
         tj = setup.traj
-        np.testing.assert_array_equal(np.float32(tj["v_min"]), z["const_rom_v_min"])
-        np.testing.assert_array_equal(np.float32(tj["v_max"]), z["const_rom_v_max"])
+        # (with the staged curriculum on, the constructor has already applied stage 0: legged_robot_trajectory.py:78-79)
+        sv = setup.stage_values(0 if setup.use_curriculum else None)
+        np.testing.assert_array_equal(np.float32(sv["v_min"]), z["const_rom_v_min"])
+        np.testing.assert_array_equal(np.float32(sv["v_max"]), z["const_rom_v_max"])
         np.testing.assert_array_equal(np.tile(np.float32(tj["obs_scale"]), (tj["N"], 1)), z["const_trajectory_scale"])
-        np.testing.assert_array_equal(np.float32(tj["max_rom_dist"]), z["const_max_rom_distance"])
+        np.testing.assert_array_equal(np.float32(sv["max_rom_dist"]), z["const_max_rom_distance"])
         assert (tj["N"], tj["dN"], tj["rom_dt"]) == (meta["traj_N"], meta["traj_dN"], meta["rom_dt"])
-        assert (tj["t_low"], tj["t_high"], tj["freq_low"], tj["freq_high"]) == (meta["t_low"], meta["t_high"], meta["freq_low"], meta["freq_high"])
+        assert (sv["t_low"], sv["t_high"], tj["freq_low"], tj["freq_high"]) == (meta["t_low"], meta["t_high"], meta["freq_low"], meta["freq_high"])
         assert tj["prob_stationary"] == meta["prob_stationary"] and tj["zero_rom_dist_llh"] == meta["zero_rom_dist_llh"]
         assert tj["push_t"] == meta["time_between_pushes"] and tj["max_push_vel_xy"] == meta["max_push_vel_xy"]
         xt = setup.extra_terms
         np.testing.assert_array_equal(np.float32(xt["tracking_rom"].w), z["const_reward_weighting"])
-        assert xt["tracking_rom"].sigma == meta["tracking_sigma"]
+        assert sv["tracking_sigma"] == meta["tracking_sigma"]
         assert (xt["differential_error"].neg, xt["differential_error"].pos) == (meta["neg_slope"], meta["pos_slope"])
         assert capi.tslots(setup.num_dof)["noise"] + meta["num_obs"] == meta["slots"]["K"]
         assert {k: v for k, v in capi.tslots(setup.num_dof).items()} == {k: v for k, v in meta["slots"].items() if k != "K"}
@@ -205,14 +234,45 @@ def _tg_rows(z, prefix, n):
     return rows
 
 
+def check_stage_against_fixture(setup, state, z, prefix, names):
+    """EnvSetup.stage_values(state) against what the reference's update_command_curriculum left in the env."""
+    v = setup.stage_values(state if setup.use_curriculum else None)
+    assert int(z[prefix + "curriculum_state"]) == state
+    np.testing.assert_allclose(np.array([v["reward_scales"][n] for n in names]), z[prefix + "stage_reward_scales"], rtol=1e-12)
+    assert v["tracking_sigma"] == float(z[prefix + "stage_tracking_sigma"])
+    np.testing.assert_array_equal(np.float32(v["v_min"]), z[prefix + "stage_v_min"])
+    np.testing.assert_array_equal(np.float32(v["v_max"]), z[prefix + "stage_v_max"])
+    assert (v["t_low"], v["t_high"]) == (float(z[prefix + "stage_t_low"]), float(z[prefix + "stage_t_high"]))
+    np.testing.assert_array_equal(np.float32(v["max_rom_dist"]), z[prefix + "stage_max_rom_distance"])
+    # reset_traj keeps reading zero_rom_dist_llh, which update_command_curriculum never writes (legged_robot_trajectory.py:73,251,531)
+    assert setup.traj["zero_rom_dist_llh"] == float(z[prefix + "stage_zero_rom_dist_llh"])
+
+
+def set_stage(env, setup, state, in_callback):
+    import ctypes as C
+    env.call("set_curriculum_stage", C.byref(setup.stage_struct(state)), int(in_callback))
+
+
 def replay_trajectory_fixture(env, z, meta):
-    """Teacher-forced replay of tests/golden/anymal_c_flat_trajectory.npz (the reference's LeggedRobotTrajectory / AnymalTrajectory
+    """Teacher-forced replay of a trajectory-env fixture (the reference's LeggedRobotTrajectory / AnymalTrajectory
     with its torch TrajectoryGenerator, oracle/gen_fixtures_trajectory.py).  Bit-exact: reset / time_out masks, episode
     lengths, last_contacts, reset count, the generator's integer-like state (ROM step counter k, stationary flag, which envs
-    were pushed / resampled -- visible through t_final and the push timers); fp32 within TOL."""
+    were pushed / resampled -- visible through t_final and the push timers); fp32 within TOL.
+    anymal_c_flat_trajectory_curriculum: the staged curriculum changes stage inside recorded steps 1 and 3 (the host stage
+    machine of the product, CurriculumClock, decides when; lg_set_curriculum_stage carries the constants).
+    anymal_c_rough_trajectory: 252 observations with the height scan, custom origins."""
+    from legged_gym_dev_amd.envs.base.env_setup import CurriculumClock
     N, A = meta["num_envs"], meta["num_dofs"]
     names = meta["reward_names"]
     ridx = [env.setup.term_row[n] for n in names]
+    setup = env.setup
+    rough = "const_height_samples" in z.files
+    clock = CurriculumClock(setup)
+    assert clock.enabled == bool(meta.get("use_curriculum", False))
+    if clock.enabled:                                       # the update at construction (legged_robot_trajectory.py:78-79)
+        set_stage(env, setup, 0, in_callback=False)
+    if "init_curriculum_state" in z.files:
+        check_stage_against_fixture(setup, 0, z, "init_", names)
 
     def install(prefix):
         for key in ("root_states", "dof_state", "last_actions", "last_dof_vel", "last_root_vel", "feet_air_time", "env_origins",
@@ -227,14 +287,22 @@ def replay_trajectory_fixture(env, z, meta):
         for k, n in enumerate(names):
             es[env.setup.term_row[n]] = z[prefix + "episode_sums"][:, k]
         env.set("episode_sums", es)
+        if rough:
+            env.set("terrain_levels", z[prefix + "terrain_levels"])
+            env.set("terrain_types", z["const_terrain_types"])
     install("init_")
-    env.set_step_counter(int(z["init_common_step_counter"]))
+    counter = int(z["init_common_step_counter"])
+    env.set_step_counter(counter)
     env.set_init_done(1)
     env.inject(1)
     dec = z["s0_sub_dof"].shape[0]
-    seen = {"reset": 0, "pushed": 0, "resampled": 0, "rom_steps": 0}
+    seen = {"reset": 0, "pushed": 0, "resampled": 0, "rom_steps": 0, "stage_changes": 0}
     for t in range(meta["n_steps"]):
         p = f"s{t}_"
+        counter += 1
+        if clock.tick(counter):                             # legged_robot_trajectory.py:414-417, decided on the host as there
+            set_stage(env, setup, clock.state, in_callback=True)
+            seen["stage_changes"] += 1
         env.set("episode_length", z[p + "pre_episode_length_buf"])
         env.set_actions(z[p + "actions"])
         for k in range(dec):
@@ -244,6 +312,8 @@ def replay_trajectory_fixture(env, z, meta):
         env.set("root_states", z[p + "new_root"])
         env.set("contact_forces", z[p + "contact_forces"])
         env.set("inject_uniforms", np.nan_to_num(z[p + "uniforms"], nan=0.5))
+        if p + "inj_level" in z.files:
+            env.set("inject_levels", np.maximum(z[p + "inj_level"], 0))
         k_before, tf_before = env.get("tg_state")[:, capi.TG_FIELDS["k"][0]].copy(), env.get("tg_state")[:, capi.TG_FIELDS["t_final"][0]].copy()
         env.call("post_physics_step")
         env.sync()
@@ -271,6 +341,12 @@ def replay_trajectory_fixture(env, z, meta):
         if int(z[p + "n_reset"]) > 0:
             np.testing.assert_allclose(env.get("extras_episode")[ridx], z[p + "extras_episode"], rtol=1e-4, atol=1e-5,
                                        err_msg=p + "extras episode means")
+        if rough:
+            np.testing.assert_allclose(env.get("measured_heights"), z[p + "measured_heights"], err_msg=p + "heights", **TOL)
+            np.testing.assert_array_equal(env.get("terrain_levels"), z[p + "post_terrain_levels"], err_msg=p + "levels")
+            np.testing.assert_allclose(env.get("env_origins"), z[p + "post_env_origins"], err_msg=p + "env_origins", **TOL)
+        if p + "post_curriculum_state" in z.files:
+            check_stage_against_fixture(setup, clock.state, z, p + "post_", names)
         np.testing.assert_allclose(env.get("lstm_h"), z[p + "post_lstm_h"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_h")
         np.testing.assert_allclose(env.get("lstm_c"), z[p + "post_lstm_c"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_c")
         rst = z[p + "reset"].astype(bool)
@@ -279,7 +355,8 @@ def replay_trajectory_fixture(env, z, meta):
         seen["resampled"] += int(((want[:, capi.TG_FIELDS["t_final"][0]] != tf_before) & ~rst).sum())
         seen["rom_steps"] += int(((want[:, capi.TG_FIELDS["k"][0]] != k_before) & ~rst).sum())
     # the fixture exercised every event of the variant
-    assert seen["reset"] > 20 and seen["pushed"] > 20 and seen["resampled"] >= 5 and seen["rom_steps"] > 40, seen
+    assert seen["reset"] > 20 and seen["pushed"] > 20 and seen["resampled"] >= 4 and seen["rom_steps"] > 40, seen
+    assert seen["stage_changes"] == (2 if clock.enabled else 0), seen
 
 
 def replay_fixture(env, z, meta, torque_tol=None, report=None):
@@ -287,17 +364,39 @@ def replay_fixture(env, z, meta, torque_tol=None, report=None):
 
     Bit-exact: reset / time_out masks, episode lengths, terrain levels, last_contacts, reset count.
     fp32 within TOL (rtol=atol=2e-5; torques from the actuator net 1e-4 abs): everything else."""
+    from legged_gym_dev_amd.envs.base.env_setup import CurriculumClock
     N, A = meta["num_envs"], meta["num_dofs"]
     names = meta["reward_names"]
     ridx = [env.setup.term_row[n] for n in names]
     ttol = torque_tol or dict(rtol=1e-4, atol=2e-4)
     load_state(env, z, "init_", meta)
-    env.set_step_counter(int(z["init_common_step_counter"]))
+    counter = int(z["init_common_step_counter"])
+    env.set_step_counter(counter)
     env.set_init_done(1)
     env.inject(1)
+    setup = env.setup
+    clock = CurriculumClock(setup)                         # the product's stage machine (legged_robot.py:360-363)
+    assert clock.enabled == bool(meta.get("use_curriculum", False))
+
+    def check_stage(prefix):
+        if prefix + "curriculum_state" not in z.files:
+            return
+        v = setup.stage_values(clock.state if clock.enabled else None)
+        assert int(z[prefix + "curriculum_state"]) == clock.state
+        assert v["push_time"] == float(z[prefix + "stage_push_time"]) and v["max_push_vel"] == float(z[prefix + "stage_max_push_vel"])
+        np.testing.assert_array_equal(np.array([v["command_ranges"][k] for k in ("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")]),
+                                      z[prefix + "stage_command_ranges"])
+    if clock.enabled:                                      # the update inside _parse_cfg (legged_robot.py:828-829)
+        set_stage(env, setup, 0, in_callback=False)
+    check_stage("init_")
     dec = z["s0_sub_dof"].shape[0]
+    changes = 0
     for t in range(meta["n_steps"]):
         p = f"s{t}_"
+        counter += 1
+        if clock.tick(counter):
+            set_stage(env, setup, clock.state, in_callback=True)
+            changes += 1
         env.set("episode_length", z[p + "pre_episode_length_buf"])   # generator edits it before step 2
         env.set_actions(z[p + "actions"])
         for k in range(dec):
@@ -340,8 +439,10 @@ def replay_fixture(env, z, meta, torque_tol=None, report=None):
         if meta["use_lstm"]:
             np.testing.assert_allclose(env.get("lstm_h"), z[p + "post_lstm_h"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_h")
             np.testing.assert_allclose(env.get("lstm_c"), z[p + "post_lstm_c"], rtol=1e-4, atol=1e-5, err_msg=p + "lstm_c")
+        check_stage(p + "post_")
         if report is not None:
             report.append((t, float(np.abs(env.get("obs") - z[p + "obs"]).max())))
+    assert changes == (2 if clock.enabled else 0)
 
 
 class HipHandle:

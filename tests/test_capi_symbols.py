@@ -42,13 +42,13 @@ def test_ctypes_structs_match_header_sizes(lib):
     # layout guard: sizes computed from the header with the C compiler must equal the ctypes mirrors
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "legged_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(lg_model),' \
-          'sizeof(lg_cfg),sizeof(lg_buffers),sizeof(lg_ppo_cfg),sizeof(lg_ppo_buffers));return 0;}\n'
+    src = '#include <stdio.h>\n#include "legged_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",sizeof(lg_model),' \
+          'sizeof(lg_cfg),sizeof(lg_buffers),sizeof(lg_ppo_cfg),sizeof(lg_ppo_buffers),sizeof(lg_stage));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    got = [ctypes.sizeof(c) for c in (capi.lg_model, capi.lg_cfg, capi.lg_buffers, capi.lg_ppo_cfg, capi.lg_ppo_buffers)]
+    got = [ctypes.sizeof(c) for c in (capi.lg_model, capi.lg_cfg, capi.lg_buffers, capi.lg_ppo_cfg, capi.lg_ppo_buffers, capi.lg_stage)]
     assert [int(v) for v in out] == got
 
 

@@ -61,24 +61,31 @@ def test_actuator_lstm_golden(oracle_built):
 
 
 TRAJ = "anymal_c_flat_trajectory"
+TRAJ_FIXTURES = [TRAJ, "anymal_c_flat_trajectory_curriculum", "anymal_c_rough_trajectory"]
 
 
-def test_trajectory_setup_matches_reference_constants():
+@pytest.mark.parametrize("name", TRAJ_FIXTURES)
+def test_trajectory_setup_matches_reference_constants(name):
     """Host setup of the trajectory-tracking variant against what the reference's LeggedRobotTrajectory
     derived: index sets, gains, noise vector (trajectory block unscaled), reward order incl. the two extra terms, ROM bounds,
     generator parameters, slot layout."""
-    z, meta = harness.load_fixture(TRAJ)
-    setup, _ = harness.make_setup(TRAJ, z, meta)
+    z, meta = harness.load_fixture(name)
+    setup, _ = harness.make_setup(name, z, meta)
     harness.check_setup_against_fixture(setup, z, meta)
     assert setup.xterm_names == ["tracking_rom", "differential_error"]
 
 
-def test_oracle_replays_reference_trajectory_steps(oracle_built):
-    """The oracle's trajectory env (lgo_traj.cpp + the traj branches of lgo_env.cpp) against six steps of the reference's own
-    LeggedRobotTrajectory / AnymalTrajectory / TrajectoryGenerator: this is what pins it."""
-    z, meta = harness.load_fixture(TRAJ)
-    setup, _ = harness.make_setup(TRAJ, z, meta)
-    env = oracle_built.OracleEnv(setup)
+@pytest.mark.parametrize("name", TRAJ_FIXTURES)
+def test_oracle_replays_reference_trajectory_steps(name, oracle_built):
+    """The oracle's trajectory env (lgo_traj.cpp + the traj branches of lgo_env.cpp) against the recorded steps of the reference's
+    own LeggedRobotTrajectory / AnymalTrajectory / TrajectoryGenerator: this is what pins it.  The curriculum fixture changes
+    stage inside steps 1 and 3 (reward scales, tracking sigma, ROM input bounds, hold-time sampler, start-offset range: the
+    callback of the change step still resamples with the old stage, its resets with the new one); the rough-terrain fixture
+    carries the height scan and the 252-wide observation."""
+    z, meta = harness.load_fixture(name)
+    setup, _ = harness.make_setup(name, z, meta)
+    hs = z["const_height_samples"] if "const_height_samples" in z.files else None
+    env = oracle_built.OracleEnv(setup, hs)
     try:
         harness.replay_trajectory_fixture(env, z, meta)
     finally:
