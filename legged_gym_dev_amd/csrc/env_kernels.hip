@@ -460,7 +460,7 @@ __device__ __forceinline__ float term_scale(const lg_cfg &c, int k) {
 }
 
 // reset_traj (LT:222-229) + the stale-trajectory error of LT:199 for one env; root already holds the post-reset pose
-__device__ void reset_trajectory(const DevParams *P, int i, int64_t counter, int inject) {
+__device__ __forceinline__ void reset_trajectory(const DevParams *P, int i, int64_t counter, int inject) {
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions;
     const float *r = P->buf.root_states + (size_t)i * 13;
@@ -535,7 +535,7 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
 // that resets would otherwise keep one lane busy for ~2.5 k instructions -- 20+ Philox draws, ~150 stores -- while the
 // block's other lanes wait, and the kernel lasts as long as its slowest block).  Same arithmetic, same Philox slots, so
 // the result is bit-identical to reset_env; only who computes what changes.  Call from all threads (contains barriers).
-__device__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
+__device__ __forceinline__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions, N = c.num_envs, F = c.num_feet, tid = threadIdx.x;
     float *r = P->buf.root_states + (size_t)i * 13;
@@ -940,8 +940,10 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
 #undef STAMP
 }
 
+// One to two waves per SIMD: at 4096 envs the launch is 256 workgroups on 256 CUs (one wave per SIMD), so the default register
+// budget of four-wave occupancy (128 VGPRs, with 212 B/lane of scratch on the phase-A lane's latency chain) bought nothing.
 template <int TILE>
-__global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *__restrict__ P, int64_t counter, int inject,
+__global__ void __launch_bounds__(LG_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) k_post_step(const DevParams *__restrict__ P, int64_t counter, int inject,
                                                                int init_done, int push_now) {
     post_step_tile<TILE>(P, (int)blockIdx.x * TILE, counter, inject, init_done, push_now);
 }

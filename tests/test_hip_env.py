@@ -612,12 +612,14 @@ def test_baseline_config3_eight_shards_equal_unsharded_32768():
         full.reset()
         g = torch.Generator(device="cuda").manual_seed(11)
         ep = torch.randint(0, 1001, (N,), device="cuda", generator=g)
-        mover = (torch.arange(N, device="cuda") % 97) == 0              # walked 4.5 m: level up at its time-out
+        mover = (torch.arange(N, device="cuda") % 97) == 0              # walked 6 m: level up at its time-out
+        top = (torch.arange(N, device="cuda") % 194) == 0               # ... half of them from the top row: wrap to a random level
         ep[mover] = 1001
         shift = torch.zeros(N, 13, device="cuda")
-        shift[mover, 0] = 4.5
+        shift[mover, 0] = 6.0
         full.episode_length_buf = ep
         t["root_states"].add_(shift)
+        t["terrain_levels"][top] = 9
         lv0 = t["terrain_levels"].clone()
         acts = [torch.randn(N, 12, device="cuda", generator=g) * (2.0 if s % 5 == 3 else 0.6) for s in range(12)]
         names = ("obs", "rew", "reset", "time_out", "terrain_levels", "env_origins", "measured_heights", "root_states", "dof_state",
@@ -629,8 +631,8 @@ def test_baseline_config3_eight_shards_equal_unsharded_32768():
             want.append({k: t[k].clone() for k in names})
             n_reset += int(t["n_reset"][0])
         moved = int((t["terrain_levels"] != lv0).sum())
-        wrapped = int(((lv0 == 9) & mover & (t["terrain_levels"] != 9)).sum())
-        assert n_reset >= 300 and moved >= 300 and wrapped > 0, (n_reset, moved, wrapped)
+        wrapped = int((top & (t["terrain_levels"] != 9)).sum())
+        assert n_reset >= 300 and moved >= 300 and wrapped > 100, (n_reset, moved, wrapped)
         assert int(t["fault_total"][0]) == 0
         consts = {k: t[k].clone() for k in ("terrain_types", "env_origins", "friction", "base_mass_delta")}
         for r in range(W):
@@ -646,6 +648,7 @@ def test_baseline_config3_eight_shards_equal_unsharded_32768():
             s.reset()
             s.episode_length_buf = ep[lo:hi]
             st["root_states"].add_(shift[lo:hi])
+            st["terrain_levels"][top[lo:hi]] = 9
             resets = 0
             for step, a in enumerate(acts):
                 s.step(a[lo:hi].contiguous())
