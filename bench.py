@@ -38,13 +38,15 @@ def macs_per_sample(obs, hidden, actions):
     return sum(a * b for a, b in zip(dims_a[:-1], dims_a[1:])) + sum(a * b for a, b in zip(dims_c[:-1], dims_c[1:]))
 
 
-def make_runner(num_envs, hidden, device, rank, world):
-    from legged_gym_dev_amd.envs import task_registry  # noqa: F401  (registers tasks)
-    from legged_gym_dev_amd.envs.anymal_c.flat.anymal_c_flat_config import AnymalCFlatCfg, AnymalCFlatCfgPPO
+def make_runner(num_envs, hidden, device, rank, world, task="anymal_c_flat"):
+    """env + runner of a registered task as a user builds them (task_registry.get_cfgs: the reference's cfg values; rough-terrain
+    tasks on the full 10 x 20 tile terrain), with the policy widths of the bench line."""
+    import copy
+    import numpy as np
+    from legged_gym_dev_amd.envs import task_registry
     from legged_gym_dev_amd.utils.helpers import class_to_dict, get_args, parse_sim_params
-    from legged_gym_dev_amd.envs.anymal_c.anymal import Anymal
     from legged_gym_dev_amd.rl.runner import OnPolicyRunner
-    env_cfg, train_cfg = AnymalCFlatCfg(), AnymalCFlatCfgPPO()
+    env_cfg, train_cfg = (copy.deepcopy(c) for c in task_registry.get_cfgs(task))
     env_cfg.env.num_envs = num_envs
     env_cfg.seed = 1
     train_cfg.policy.actor_hidden_dims = list(hidden)
@@ -52,11 +54,10 @@ def make_runner(num_envs, hidden, device, rank, world):
     args = get_args([])
     args.sim_device = args.rl_device = device
     torch.manual_seed(1)
-    import numpy as np
     np.random.seed(1)
     sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
     kw = {"rank": rank, "world_size": world} if world > 1 else {}
-    env = Anymal(env_cfg, sim_params, args.physics_engine, device, True, **kw)
+    env = task_registry.task_classes[task](env_cfg, sim_params, args.physics_engine, device, True, **kw)
     runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device=device)
     return env, runner
 
@@ -95,7 +96,7 @@ def time_iterations(runner, steps, warmup, world):
     return el, t_roll * steps
 
 
-def gemm_roofline(runner, hidden):
+def gemm_roofline(runner, hidden, with_largest=True):
     """GEMM group of one minibatch (forward + head + backward of actor and critic: everything lg_ppo_minibatch_backward
     launches), timed live with HIP events on the launch stream INSIDE a real update -- begin_update, then epochs x minibatches
     of {backward, optimiser step} as HipPPO.update() runs them, the events bracketing each backward (the optimiser step, which
@@ -129,7 +130,7 @@ def gemm_roofline(runner, hidden):
             traffic = pm["gemm_group_bytes_per_minibatch"]
     except (OSError, ValueError, KeyError):
         pass
-    big = single_gemm_roofline(R, hidden)
+    big = single_gemm_roofline(R, hidden) if with_largest else None
     return {"bound": "mfma", "kernel": "k_gemm<split-bf16 x6, mfma_f32_32x32x16_bf16> (ActorCritic fwd+bwd of one minibatch)",
             "achieved": round(ach, 3), "peak": round(MFMA_X6_PEAK_TF, 1), "unit": "TFLOP/s", "frac": round(ach / MFMA_X6_PEAK_TF, 4),
             "traffic": traffic, "flops_per_minibatch": flops, "ms_per_minibatch": round(ms, 4), "gemm_launches": n_launch,
@@ -259,6 +260,45 @@ def cpu_baseline(num_envs, hidden):
                       f"+ {E * MB} minibatch updates of {R} rows ({t_upd:.2f}s); {cores} threads"}
 
 
+def lg_step_us(env, reps=50):
+    """us per lg_step (control loop + post-step + finalize) on the env's current state, HIP events on the launch stream."""
+    a = torch.zeros(env.num_envs, env.num_actions, device=env.device)
+    env.core.step(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        env.core.step(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def other_config(task, num_envs, hidden, device, steps=6, warmup=3):
+    """BASELINE.json configs[2] / configs[4] beside the bench line: the same whole-iteration measurement on another task."""
+    env, runner = make_runner(num_envs, hidden, device, 0, 1, task=task)
+    try:
+        env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        el, t_roll = time_iterations(runner, steps, warmup, 1)
+        rf = gemm_roofline(runner, hidden, with_largest=False)
+        ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
+        iters = steps + warmup + 2 + 1                     # timed + warm-up + the two split iterations + the roofline's update
+        out = {"task": task, "num_envs": num_envs, "num_obs": env.num_obs, "policy_hidden": list(hidden),
+               "terrain": (f"{env.cfg.terrain.mesh_type} {env.cfg.terrain.num_rows}x{env.cfg.terrain.num_cols} tiles, "
+                           f"{env.terrain.tot_rows}x{env.terrain.tot_cols} height samples") if env.terrain is not None else "plane",
+               "value": round(runner.num_steps_per_env * num_envs * steps / el, 1), "unit": "env-steps/s",
+               "ms_per_step": round(1e3 * el / steps, 3), "rollout_ms": round(1e3 * t_roll / steps, 3),
+               "update_ms": round(1e3 * (el - t_roll) / steps, 3),
+               "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "ms_per_minibatch", "flops_per_minibatch")},
+               "us_per_lg_step": round(lg_step_us(env), 2),
+               "resets_per_env_step": round(ep_done / max(runner.num_steps_per_env * num_envs * (iters - 1), 1), 5),
+               "physics_fault_resets": int(env.fault_total.cpu())}
+        return out
+    finally:
+        env.close()
+        runner.ppo.close()
+
+
 def rank_environments(n, port, base=None, comm_port=None):
     """Environment of each of the n child ranks (what torch.distributed.run would export)."""
     base = dict(os.environ if base is None else base)
@@ -332,6 +372,8 @@ def main():
     ap.add_argument("--hidden", type=str, default="512,256,128")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt", action="store_true", help="skip the [128,64,32] pass (profiling runs)")
+    ap.add_argument("--no_other", action="store_true", help="skip the anymal_c_rough / cassie passes (BASELINE configs[2], [4])")
+    ap.add_argument("--sustained", type=int, default=300, help="iterations of the sustained-speed pass after the timed steps (0: skip)")
     args = ap.parse_args()
     hidden = [int(v) for v in args.hidden.split(",")]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -361,6 +403,20 @@ def main():
     env, runner = make_runner(args.num_envs, hidden, device, rank, world)
     el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world
+    sustained = None
+    if args.sustained > 0 and world == 1:
+        # the timed K steps are a burst of a few hundred ms; a training run settles at the power / thermal state of minutes
+        # of load.  Same loop, `sustained` iterations, no host synchronisation inside.
+        ar = runner._grad_reduce
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.sustained):
+            runner.rollout()
+            runner.ppo.update(ar)
+        torch.cuda.synchronize()
+        s_el = time.perf_counter() - t0
+        sustained = {"iterations": args.sustained, "value": round(steps_per_iter * args.sustained / s_el, 1), "unit": "env-steps/s",
+                     "ms_per_step": round(1e3 * s_el / args.sustained, 3), "seconds": round(s_el, 2)}
     out = {"metric": f"env-steps/sec (whole node), ANYmal-C flat {args.num_envs} envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -373,7 +429,9 @@ def main():
     # what the number was measured on: how often the random-init policy makes robots fall, and whether the
     # physics fault guard ever fired (it must not)
     ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
-    steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2)
+    steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2 + (args.sustained if sustained else 0))
+    if sustained:
+        out["sustained"] = sustained
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
     out["config"]["physics_fault_resets"] = int(env.fault_total.cpu())
     if rank == 0 and world == 1:
@@ -381,9 +439,11 @@ def main():
         out["roofline"]["traffic_source"] = ("committed PMC passes of this command (profiles/" + PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / "
                                              "WRITE_SIZE in separate runs); not collected during this run")
         out["roofline_env_step"] = env_roofline(env)
+        env.close()
+        runner.ppo.close()
+        if not args.no_other:
+            out["other_configs"] = [other_config(t, args.num_envs, hidden, device) for t in ("anymal_c_rough", "cassie")]
         if tuple(hidden) != (128, 64, 32) and not args.no_alt:
-            env.close()
-            runner.ppo.close()
             env2, runner2 = make_runner(args.num_envs, [128, 64, 32], device, rank, world)
             el2, tr2 = time_iterations(runner2, max(3, args.steps // 2), 2, world)
             n2 = max(3, args.steps // 2)

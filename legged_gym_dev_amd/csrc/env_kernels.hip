@@ -327,6 +327,8 @@ struct RewardCtx {
     float *air;         // feet_air_time / last_contacts rows of this env (LDS copies: the stateful feet_air_time term updates them)
     uint8_t *lc;
     V3 blv, bav, pg;
+    const float *fr;    // the same three frame vectors as 9 floats in LDS: what signal_at indexes (a select chain over the V3
+                        // members made the compiler keep this whole struct in scratch)
     const float *cmd, *cf, *tau, *act, *lact, *lqd;
     const float *dof;   // interleaved q, qd
     float root_z;
@@ -412,9 +414,9 @@ __device__ float reward_term(const DevParams *P, int i, int k, const RewardCtx &
 __device__ float signal_at(const DevParams *P, int i, int sig, int k, const RewardCtx &x) {
     const lg_cfg &c = P->cfg;
     switch (sig) {
-    case LG_SIG_BASE_LIN_VEL: return k == 0 ? x.blv.x : k == 1 ? x.blv.y : x.blv.z;
-    case LG_SIG_BASE_ANG_VEL: return k == 0 ? x.bav.x : k == 1 ? x.bav.y : x.bav.z;
-    case LG_SIG_PROJ_GRAVITY: return k == 0 ? x.pg.x : k == 1 ? x.pg.y : x.pg.z;
+    case LG_SIG_BASE_LIN_VEL: return x.fr[k];
+    case LG_SIG_BASE_ANG_VEL: return x.fr[3 + k];
+    case LG_SIG_PROJ_GRAVITY: return x.fr[6 + k];
     case LG_SIG_COMMANDS: return x.cmd[k];
     case LG_SIG_ROOT_POS: return P->buf.root_states[(size_t)i * 13 + k];
     case LG_SIG_TRAJ0: return P->buf.trajectory[(size_t)i * (c.traj.enabled ? c.traj.N : 1) * 2 + k];
@@ -460,7 +462,10 @@ __device__ __forceinline__ float term_scale(const lg_cfg &c, int k) {
 }
 
 // reset_traj (LT:222-229) + the stale-trajectory error of LT:199 for one env; root already holds the post-reset pose
-__device__ __forceinline__ void reset_trajectory(const DevParams *P, int i, int64_t counter, int inject) {
+// Inlined into their callers: as separate functions they cost k_post_step a call frame in scratch (saved registers on the
+// phase-A latency chain) and the callee's register interface -- post-step 17.3 -> 14.5 us flat, 29.2 -> 25.1 us rough terrain
+// (profiles/r03_ab.txt).
+__device__ __forceinline__ void reset_trajectory(const DevParams *P, int i, int64_t counter, int inject, float *__restrict__ win) {
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions;
     const float *r = P->buf.root_states + (size_t)i * 13;
@@ -469,7 +474,7 @@ __device__ __forceinline__ void reset_trajectory(const DevParams *P, int i, int6
         zx += (c.traj.max_rom_dist[0] - (-c.traj.max_rom_dist[0])) * uni(P, i, LG_TSLOT_ROMD(A) + 1, counter, inject) + (-c.traj.max_rom_dist[0]);
         zy += (c.traj.max_rom_dist[1] - (-c.traj.max_rom_dist[1])) * uni(P, i, LG_TSLOT_ROMD(A) + 2, counter, inject) + (-c.traj.max_rom_dist[1]);
     }
-    tg_reset(P, i, zx, zy, counter, inject);
+    tg_reset(P, i, zx, zy, counter, inject, win);
     for (int k = 0; k < 2; ++k) {
         const float d = P->buf.trajectory[(size_t)i * c.traj.N * 2 + k] - r[k];
         P->buf.prev_error[(size_t)i * 2 + k] = d * d;
@@ -477,7 +482,8 @@ __device__ __forceinline__ void reset_trajectory(const DevParams *P, int i, int6
 }
 
 // LR:147-187 (+:415-454, :463-486, AN:56-60) for one env
-__device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
+// win: LG_TG_WIN floats of LDS for this lane (trajectory env: the generator's window while it is rebuilt)
+__device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject, int init_done, float *__restrict__ win) {
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions, N = c.num_envs;
     float *r = P->buf.root_states + (size_t)i * 13;
@@ -513,7 +519,7 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
     if (c.custom_origins)
         for (int k = 0; k < 2; ++k) r[k] += (1.0f - (-1.0f)) * uni(P, i, s_xy + k, counter, inject) + (-1.0f);
     for (int k = 0; k < 6; ++k) r[7 + k] = (0.5f - (-0.5f)) * uni(P, i, s_vel + k, counter, inject) + (-0.5f);
-    if (tj) reset_trajectory(P, i, counter, inject);
+    if (tj) reset_trajectory(P, i, counter, inject, win);
     else resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject, c.cmd_lo, c.cmd_hi);
     for (int j = 0; j < A; ++j) { P->buf.last_actions[(size_t)i * A + j] = 0.0f; P->buf.last_dof_vel[(size_t)i * A + j] = 0.0f; }
     for (int f = 0; f < c.num_feet; ++f) P->buf.feet_air_time[(size_t)i * c.num_feet + f] = 0.0f;
@@ -535,7 +541,7 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
 // that resets would otherwise keep one lane busy for ~2.5 k instructions -- 20+ Philox draws, ~150 stores -- while the
 // block's other lanes wait, and the kernel lasts as long as its slowest block).  Same arithmetic, same Philox slots, so
 // the result is bit-identical to reset_env; only who computes what changes.  Call from all threads (contains barriers).
-__device__ __forceinline__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int inject, int init_done) {
+__device__ __forceinline__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int inject, int init_done, float *__restrict__ win) {
     const lg_cfg &c = P->cfg;
     const int A = c.num_actions, N = c.num_envs, F = c.num_feet, tid = threadIdx.x;
     float *r = P->buf.root_states + (size_t)i * 13;
@@ -593,7 +599,7 @@ __device__ __forceinline__ void reset_env_coop(const DevParams *P, int i, int64_
     }
     __syncthreads();
     if (tj) {                                                      // needs the new root pose: after the barrier, one lane (a serial 10-step
-        if (tid == 0) reset_trajectory(P, i, counter, inject);     // ROM integration; resets are rare)
+        if (tid == 0) reset_trajectory(P, i, counter, inject, win);   // ROM integration; resets are rare)
         __syncthreads();
     }
 }
@@ -717,6 +723,8 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     //   A3  all lanes: episode sums (+ the logging sums of the envs that reset).
     static_assert(TILE * 16 == LG_TILE_THREADS, "phase A: 16 lanes per environment");
     __shared__ float s_tv[TILE][LG_NUM_TERMS];
+    __shared__ float s_fr[TILE][9];
+    __shared__ float s_win[TILE][LG_TG_WIN];                          // trajectory env: the generator window of each env's phase-A lane
     __shared__ float s_js[TILE][JS_N];
     __shared__ uint8_t s_rst[TILE];
     const int e16 = tid >> 4, l16 = tid & 15;
@@ -760,12 +768,18 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
         x.blv = quat_rotate_inverse(r + 3, V3{r[7], r[8], r[9]});        // LR:118-121
         x.bav = quat_rotate_inverse(r + 3, V3{r[10], r[11], r[12]});
         x.pg = quat_rotate_inverse(r + 3, V3{0.0f, 0.0f, -1.0f});
+        {
+            float *f = s_fr[e16];
+            f[0] = x.blv.x; f[1] = x.blv.y; f[2] = x.blv.z; f[3] = x.bav.x; f[4] = x.bav.y; f[5] = x.bav.z;
+            f[6] = x.pg.x; f[7] = x.pg.y; f[8] = x.pg.z;
+            x.fr = f;
+        }
         bool rst = false;                                                   // LR:139-145 (contact forces do not change below)
         for (int b = 0; b < c.num_term; ++b) rst |= fnorm3(cf + 3 * c.term_idx[b]) > 1.0f;
         const bool flt = P->fault[i] != 0;                                  // physics fault guard (lg_physics.h)
         const bool to = ep > c.max_episode_length;
         rst = rst || flt || to;
-        if (c.traj.enabled) tg_callback_step(P, i, counter, inject);       // LT:405-417
+        if (c.traj.enabled) tg_callback_step(P, i, counter, inject, s_win[e16]);   // LT:405-417
         else if (ep % c.resample_steps == 0) resample_commands(P, i, LG_SLOT_CMD, counter, inject, P->cb.cmd_lo, P->cb.cmd_hi);   // LR:348-350
         if (c.heading_command && !c.traj.enabled) {                         // LR:351-354, math.py:45-48
             V3 fwd = quat_apply(r + 3, V3{1.0f, 0.0f, 0.0f});
@@ -841,7 +855,7 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     }
     __syncthreads();
     STAMP(2);
-    for (int q = 0; q < s_cnt; ++q) reset_env_coop(P, s_list[q], counter, inject, init_done);   // workgroup-uniform trip count
+    for (int q = 0; q < s_cnt; ++q) reset_env_coop(P, s_list[q], counter, inject, init_done, s_win[0]);   // workgroup-uniform trip count
     STAMP(3);
     if (s_cnt > 0) {
         if (tid < LG_NUM_TERMS && term_scale(c, tid) != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
@@ -940,10 +954,11 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
 #undef STAMP
 }
 
-// One to two waves per SIMD: at 4096 envs the launch is 256 workgroups on 256 CUs (one wave per SIMD), so the default register
-// budget of four-wave occupancy (128 VGPRs, with 212 B/lane of scratch on the phase-A lane's latency chain) bought nothing.
+// Measured and not kept: __attribute__((amdgpu_waves_per_eu(1, 2))) (a 256-VGPR budget: the launch is one wave per SIMD at 4096
+// envs).  It removes the last scratch bytes but the allocator then parks the trajectory window in LDS (+32 KB) and the kernel
+// schedules for occupancy 2: 26.4 vs 14.5 us flat, 38.4 vs 25.1 us rough (profiles/r03_ab.txt).
 template <int TILE>
-__global__ void __launch_bounds__(LG_TILE_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) k_post_step(const DevParams *__restrict__ P, int64_t counter, int inject,
+__global__ void __launch_bounds__(LG_TILE_THREADS) k_post_step(const DevParams *__restrict__ P, int64_t counter, int inject,
                                                                int init_done, int push_now) {
     post_step_tile<TILE>(P, (int)blockIdx.x * TILE, counter, inject, init_done, push_now);
 }
@@ -1033,6 +1048,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_reset_ids(const DevParams *
                                                                 int64_t counter, int inject, int init_done) {
     const lg_cfg &c = P->cfg;
     const int N = c.num_envs, tid = threadIdx.x;
+    __shared__ float s_win[LG_TG_WIN];
     for (int q = blockIdx.x; q < n; q += gridDim.x) {         // workgroup-uniform
         const int i = ids[q];
         if (i < 0 || i >= N) continue;
@@ -1041,16 +1057,17 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_reset_ids(const DevParams *
             P->buf.episode_sums[(size_t)tid * N + i] = 0.0f;
         }
         if (tid == 0) atomicAdd(P->reset_count, 1);
-        reset_env_coop(P, i, counter, inject, init_done);
+        reset_env_coop(P, i, counter, inject, init_done, s_win);
     }
 }
 
 // reset_idx(arange(N)) (base_task.py:113): no logging
-__global__ void k_reset_all(const DevParams *__restrict__ P, int64_t counter, int inject, int init_done) {
+__global__ void __launch_bounds__(64) k_reset_all(const DevParams *__restrict__ P, int64_t counter, int inject, int init_done) {
+    __shared__ float s_win[64][LG_TG_WIN];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P->cfg.num_envs) return;
     for (int k = 0; k < LG_NUM_TERMS; ++k) P->buf.episode_sums[(size_t)k * P->cfg.num_envs + i] = 0.0f;
-    reset_env(P, i, counter, inject, init_done);
+    reset_env(P, i, counter, inject, init_done, s_win[threadIdx.x]);
     P->reset_mark[i] = 0;
 }
 

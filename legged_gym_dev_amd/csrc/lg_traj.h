@@ -81,61 +81,48 @@ __device__ inline void tg_input(const DevParams *P, int i, float tt, float v[2])
     }
 }
 
-// The window of ROM states of env i, in registers: every load issued before the first store (the buffers may alias as far as
-// the compiler knows, so a load behind a store waits for it -- one exposed round trip per point for the lone lane otherwise).
-struct TgWindow { float z[2 * LG_TRAJ_MAX_PTS]; };
-__device__ inline void tg_window_load(const DevParams *P, int i, TgWindow &w) {
+// The window of ROM states of env i while it is being stepped: a workspace of LG_TG_WIN floats in LDS handed in by the kernel
+// (one per lane that runs a generator; odd stride between lanes).  As a register array it was the one object the post-step
+// kernel kept in scratch (34 floats per lane: the allocator would not keep the dynamically indexed copy in VGPRs under that
+// kernel's register budget).  Loaded whole before the first store to the window's home in HBM, as before.
+#define LG_TG_WIN (2 * LG_TRAJ_MAX_PTS + 1)
+__device__ inline void tg_window_load(const DevParams *P, int i, float *__restrict__ w) {
     const int n2 = 2 * (P->cfg.traj.N * P->cfg.traj.dN + 1);
     const float *z = P->buf.tg_traj + (size_t)i * n2;
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; ++p) w.z[p] = p < n2 ? z[p] : 0.0f;
+    for (int p = 0; p < n2; ++p) w[p] = z[p];
 }
-__device__ inline void tg_window_store(const DevParams *P, int i, const TgWindow &w) {
+__device__ inline void tg_window_store(const DevParams *P, int i, const float *__restrict__ w) {
     const int n2 = 2 * (P->cfg.traj.N * P->cfg.traj.dN + 1);
     float *z = P->buf.tg_traj + (size_t)i * n2;
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; ++p)
-        if (p < n2) z[p] = w.z[p];
+    for (int p = 0; p < n2; ++p) z[p] = w[p];
 }
 // RD:578-592 (SingleInt2D.f RD:192-193: z+ = z + rom_dt v): shift the window by one point and append the new state
-__device__ inline void tg_window_step(const DevParams *P, TgWindow &w, const float v[2]) {
+__device__ inline void tg_window_step(const DevParams *P, float *__restrict__ w, const float v[2]) {
 #pragma clang fp contract(off)
     const lg_traj_cfg &t = P->cfg.traj;
     const int n2 = 2 * (t.N * t.dN + 1);
-    float last0 = 0.0f, last1 = 0.0f;
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; p += 2)
-        if (p == n2 - 2) { last0 = w.z[p]; last1 = w.z[p + 1]; }
-    const float z0 = last0 + t.rom_dt * v[0], z1 = last1 + t.rom_dt * v[1];
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS - 2; ++p) w.z[p] = w.z[p + 2];
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; p += 2)
-        if (p == n2 - 2) { w.z[p] = z0; w.z[p + 1] = z1; }
+    const float z0 = w[n2 - 2] + t.rom_dt * v[0], z1 = w[n2 - 1] + t.rom_dt * v[1];
+    for (int p = 0; p < n2 - 2; ++p) w[p] = w[p + 2];
+    w[n2 - 2] = z0; w[n2 - 1] = z1;
 }
 // RD:610-615: the window interpolated at the env's time (t, k already advanced)
-__device__ inline void tg_window_interpolate(const DevParams *P, int i, const TgWindow &w, float tnow, float know) {
+__device__ inline void tg_window_interpolate(const DevParams *P, int i, const float *__restrict__ w, float tnow, float know) {
 #pragma clang fp contract(off)
     const lg_traj_cfg &t = P->cfg.traj;
     const float frac = tnow - (know - 1.0f) * t.rom_dt;
     float *out = P->buf.trajectory + (size_t)i * t.N * 2;
-#pragma unroll
-    for (int p = 0; p < LG_TRAJ_MAX_PTS - 1; ++p)
-        if (p < t.N) {                                   // dN == 1 (checked at lg_create): points p and p + 1
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const float a = w.z[2 * p + d], b = w.z[2 * p + 2 + d];
-                out[2 * p + d] = a + (b - a) * frac / t.rom_dt;
-            }
+    for (int p = 0; p < t.N; ++p)                        // dN == 1 (checked at lg_create): points p and p + 1
+        for (int d = 0; d < 2; ++d) {
+            const float a = w[2 * p + d], b = w[2 * p + 2 + d];
+            out[2 * p + d] = a + (b - a) * frac / t.rom_dt;
         }
 }
 
 // LT:409-411: traj_gen.step() (RD:567-576) + get_trajectory
-__device__ inline void tg_callback_step(const DevParams *P, int i, int64_t counter, int inject) {
+__device__ inline void tg_callback_step(const DevParams *P, int i, int64_t counter, int inject, float *__restrict__ w) {
 #pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
     const lg_traj_cfg &t = P->cfg.traj;
     float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
-    TgWindow w;
     tg_window_load(P, i, w);
     const float tt = s[LG_TG_T];
     if (tt > s[LG_TG_T_FINAL]) tg_resample(P, tg_par_cb(P), i, LG_TSLOT_TG, counter, inject);
@@ -153,17 +140,13 @@ __device__ inline void tg_callback_step(const DevParams *P, int i, int64_t count
 }
 
 // RD:597-608 with the start state z0 (LT:222-229)
-__device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y, int64_t counter, int inject) {
+__device__ inline void tg_reset(const DevParams *P, int i, float z0x, float z0y, int64_t counter, int inject, float *__restrict__ w) {
 #pragma clang fp contract(off)      // one rounding per torch op: the event comparisons below must agree with the reference
     const lg_traj_cfg &t = P->cfg.traj;
     const int npts = t.N * t.dN + 1, A = P->cfg.num_actions;
     float *s = P->buf.tg_state + (size_t)i * LG_TG_STRIDE;
-    TgWindow w;
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; ++p) w.z[p] = 0.0f;
-#pragma unroll
-    for (int p = 0; p < 2 * LG_TRAJ_MAX_PTS; p += 2)
-        if (p == 2 * (npts - 1)) { w.z[p] = z0x; w.z[p + 1] = z0y; }
+    for (int p = 0; p < 2 * (npts - 1); ++p) w[p] = 0.0f;
+    w[2 * (npts - 1)] = z0x; w[2 * (npts - 1) + 1] = z0y;
     s[LG_TG_K] = -(float)(t.N * t.dN);
     s[LG_TG_T] = s[LG_TG_K] * t.rom_dt;
     s[LG_TG_T_FINAL] = s[LG_TG_K] * t.rom_dt;

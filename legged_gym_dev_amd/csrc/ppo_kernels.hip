@@ -809,7 +809,11 @@ static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
             hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 3, 1, false, true, 1, 4, PL>), grid, dim3(256), 0, s, g);
         } else {
             dim3 grid((unsigned)big_tiles, 1, nz);
-            hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 2, 1, false, true, 2, 4, PL>), grid, dim3(512), 0, s, g);
+            // LG_GEMM_W4 (A/B): the 128x128 tile on 4 waves of 64x64 (768 B of LDS traffic per MFMA) instead of 8 waves of 64x32 (1 KB)
+            static const int w4 = getenv("LG_GEMM_W4") ? atoi(getenv("LG_GEMM_W4")) : 0;
+            if ((w4 & 1) && EPI == 0 || (w4 & 2) && EPI == 1)
+                hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 2, 2, false, true, 2, 2, PL>), grid, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((k_gemm<true, B_RC, EPI, 2, 1, false, true, 2, 4, PL>), grid, dim3(512), 0, s, g);
         }
     } else {
         dim3 grid((unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)), 1, nz);
@@ -876,6 +880,9 @@ extern "C" void ppok_gemm_dw(const GemmArgs *g, int nz, int splits, hipStream_t 
     for (int z = 0; z < nz; ++z) { maxM = g->M[z] > maxM ? g->M[z] : maxM; maxN = g->N[z] > maxN ? g->N[z] : maxN; }
     const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
     if (big_tiles * splits >= 192 && maxN > 64 && maxM > 64) {
+        static const int w4 = getenv("LG_DW_W4") ? atoi(getenv("LG_DW_W4")) : 0;     // A/B: 4 waves of 64x64 per 128x128 tile
+        if (w4) hipLaunchKernelGGL((k_gemm_dw_t<2, 2, 2, 2>), dim3((unsigned)big_tiles, splits, nz), dim3(256), 0, s, *g);
+        else
         hipLaunchKernelGGL((k_gemm_dw_t<2, 1, 2, 4>), dim3((unsigned)big_tiles, splits, nz), dim3(512), 0, s, *g);
     } else {
         const unsigned tiles = ((maxM + 63) / 64) * ((maxN + 63) / 64);

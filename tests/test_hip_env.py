@@ -830,7 +830,7 @@ def test_staged_curriculum_through_the_product_env(oracle_built):
         c.curriculum.push.magnitude, c.curriculum.push.time = [0.1, 0.5, 1], [3, 2, 1]
         c.commands.ranges.lin_vel_x, c.commands.ranges.lin_vel_y = [-1.0, 1.0], [-1.0, 1.0]
         c.commands.resampling_time = 0.04                      # every 2 policy steps
-        c.domain_rand.push_interval_s = 0.04                   # nominal period 2 steps -> 6 / 4 / 2 with the stage multipliers
+        c.domain_rand.push_interval_s = 0.039                  # nominal period ceil(0.039 / dt) = 2 steps -> 6 / 4 / 2 with the stage multipliers
     env = make("anymal_c_flat", edit_base)
     try:
         assert env.curriculum_state == 0 and env.push_time == 6.0 and abs(env.max_push_vel - 0.1) < 1e-12

@@ -3,7 +3,7 @@ pat=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do
   rm -rf /tmp/kavg
-  env $kv rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kavg -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_alt > /dev/null 2>&1
+  env $kv rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kavg -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_alt --no_other --sustained 0 > /dev/null 2>&1
   python3 - "$pat" "$kv" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/kavg/**/*kernel_stats.csv", recursive=True)[0]
