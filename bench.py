@@ -404,6 +404,11 @@ def main():
     el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world
     sustained = None
+    # what the timed steps were measured on: how often the random-init policy makes robots fall, and whether the
+    # physics fault guard ever fired (it must not)
+    ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
+    steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2)
+    faults = int(env.fault_total.cpu())
     if args.sustained > 0 and world == 1:
         # the timed K steps are a burst of a few hundred ms; a training run settles at the power / thermal state of minutes
         # of load.  Same loop, `sustained` iterations, no host synchronisation inside.
@@ -415,8 +420,16 @@ def main():
             runner.ppo.update(ar)
         torch.cuda.synchronize()
         s_el = time.perf_counter() - t0
+        ep2 = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
         sustained = {"iterations": args.sustained, "value": round(steps_per_iter * args.sustained / s_el, 1), "unit": "env-steps/s",
-                     "ms_per_step": round(1e3 * s_el / args.sustained, 3), "seconds": round(s_el, 2)}
+                     "ms_per_step": round(1e3 * s_el / args.sustained, 3), "seconds": round(s_el, 2),
+                     "resets_per_env_step": round((ep2 - ep_done) / (steps_per_iter * args.sustained), 5),
+                     "physics_fault_resets": int(env.fault_total.cpu()) - faults,
+                     "policy_std_at_end": round(float(runner.ppo.param_views["std"].mean()), 3),
+                     "note": "the fork's anymal_c_flat reward is identically 0 after its positive clip (commands x, y = 0: SURVEY.md 0.8), so over "
+                             "hundreds of iterations PPO's entropy bonus alone inflates the policy's std and its actions (|a| up to the clip of "
+                             "100): robots thrash, resets per env-step rise 3x and a few envs per million steps exceed the physics guard's "
+                             "141 rad/s (tools/diag_faults.py, profiles/r03_diag_faults.txt).  Workload drift and power state both enter this figure"}
     out = {"metric": f"env-steps/sec (whole node), ANYmal-C flat {args.num_envs} envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -426,14 +439,10 @@ def main():
                       "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden, "parallelism": f"env-shard x{world}",
                       "rollout_ms": round(1e3 * t_roll / args.steps, 3),
                       "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
-    # what the number was measured on: how often the random-init policy makes robots fall, and whether the
-    # physics fault guard ever fired (it must not)
-    ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
-    steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2 + (args.sustained if sustained else 0))
     if sustained:
         out["sustained"] = sustained
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
-    out["config"]["physics_fault_resets"] = int(env.fault_total.cpu())
+    out["config"]["physics_fault_resets"] = faults
     if rank == 0 and world == 1:
         out["roofline"] = gemm_roofline(runner, hidden)
         out["roofline"]["traffic_source"] = ("committed PMC passes of this command (profiles/" + PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / "

@@ -288,6 +288,9 @@ int lg_reset_all(lg_ctx *ctx);                                 /* reset_idx(aran
  * over the ids and extras["time_outs"].  ids: DEVICE int32[n], local env indices, no duplicates.  n == 0 returns at once
  * (legged_robot.py:156-157).  Draws come from the env's reset slots at the current step counter. */
 int lg_reset_ids(lg_ctx *ctx, const int32_t *ids, int n);
+/* Runs the step's single-workgroup epilogue (extras["episode"], extras["time_outs"], counters) if a learner attached with
+ * lg_ppo_attach_env left it pending; a no-op otherwise.  Every env entry point does this itself before it touches the env. */
+int lg_finalize(lg_ctx *ctx);
 int lg_get_stage(lg_ctx *ctx, lg_stage *out);          /* the values in force (at creation: what lg_cfg holds) */
 int lg_set_curriculum_stage(lg_ctx *ctx, const lg_stage *stage, int in_callback);
 
@@ -296,7 +299,7 @@ int lg_set_curriculum_stage(lg_ctx *ctx, const lg_stage *stage, int in_callback)
 typedef struct lg_ppo_cfg {
     int32_t num_envs, num_obs, num_critic_obs, num_actions;
     int32_t num_hidden, actor_hidden[LG_MAX_HIDDEN], critic_hidden[LG_MAX_HIDDEN];
-    int32_t activation /*0 elu, 1 selu, 2 relu, 3 lrelu, 4 tanh, 5 sigmoid (rsl_rl get_activation; crelu rejected)*/, num_steps, num_epochs, num_mini_batches;
+    int32_t activation /*0 elu, 1 selu, 2 relu, 3 lrelu, 4 tanh, 5 sigmoid (rsl_rl get_activation; its "crelu" is nn.ReLU: 2)*/, num_steps, num_epochs, num_mini_batches;
     int32_t adaptive_schedule, use_clipped_value_loss, world_size, _pad;
     uint64_t seed;
     float init_noise_std, value_loss_coef, clip_param, entropy_coef, learning_rate;
@@ -342,6 +345,12 @@ int lg_ppo_begin_update(lg_ppo *p);                /* new permutation, zero loss
 int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb);   /* fwd, loss, bwd -> grads (+KL tail) */
 int lg_ppo_minibatch_step(lg_ppo *p);              /* KL-adaptive lr, clip_grad_norm, Adam; clears grads */
 int lg_ppo_end_update(lg_ppo *p);                  /* finalise mean losses, clear storage */
+/* Rollout fusion (optional; OnPolicyRunner.rollout switches it on for the duration of a rollout).  With an env attached, lg_step
+ * leaves its single-workgroup epilogue pending and lg_ppo_process_env_step only records its arguments; both run inside the launch
+ * of the NEXT lg_ppo_act (extra workgroups beside the two MLPs: 5 launches per policy step become 3).  Any other entry point of
+ * either object, and lg_ppo_attach_env(p, NULL), first runs what is pending the ordinary way, so results are identical.
+ * While attached, extras / n_reset / the logging sums of a step become visible with the next lg_ppo_act (or flush). */
+int lg_ppo_attach_env(lg_ppo *p, lg_ctx *env);
 /* The caller wrote lg_ppo_buffers.params itself (checkpoint load, a broadcast of its own): the weight images the rollout forward
  * reads are re-derived by the next lg_ppo_act.  (lg_ppo_minibatch_step and lg_ppo_broadcast_params mark them stale themselves.) */
 int lg_ppo_params_changed(lg_ppo *p);

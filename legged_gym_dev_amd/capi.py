@@ -192,6 +192,8 @@ def declare_env_api(lib, prefix="lg_"):
     for n in ("compute_torques", "simulate", "post_physics_step", "reset_all"):
         g(n).argtypes = [vp]
     g("reset_ids").argtypes = [vp, vp, C.c_int]
+    if prefix == "lg_":
+        g("finalize").argtypes = [vp]
     g("get_stage").argtypes = [vp, C.POINTER(lg_stage)]
     g("set_curriculum_stage").argtypes = [vp, C.POINTER(lg_stage), C.c_int]
     if prefix == "lg_":

@@ -11,7 +11,9 @@ void lg_set_error(const std::string &s) { g_err = s; }
 
 extern "C" void lgk_set_actions(const DevParams *P, const float *a, int n, hipStream_t s);
 extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s);
-extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, int push_now, hipStream_t s);
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, int push_now, int finalize,
+                              hipStream_t s);
+extern "C" void lgk_finalize(const DevParams *P, int accumulate, hipStream_t s);
 extern "C" void lgk_set_stage(DevParams *P, const lg_stage *st, int what, hipStream_t s);
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s);
 extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int N, int64_t counter, int inject, int init_done, int traj,
@@ -46,6 +48,7 @@ int lg_version(void) { return 1; }
 
 int lg_destroy(lg_ctx *c) {
     if (!c) return 0;
+    if (c->d) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
     delete c;
     return 0;
@@ -190,7 +193,11 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
         DA(b.prev_error, (size_t)N * 2); DA(b.push_timer, N); DA(h.reset_mark, N); DA(h.dbg_cycles, 64 * 8);
     }
     DA(b.inject_uniforms, (size_t)N * h.K); DA(b.inject_levels, N); DA(b.material, (size_t)N * 4);
-    DA(h.ep_accum, LG_NUM_TERMS); DA(h.reset_count, 1); DA(h.fault, N);
+    DA(h.ep_accum, LG_NUM_TERMS); DA(h.reset_count, 1); DA(h.fault, N); DA(h.any_reset_step, 1);
+    {
+        const int64_t never = -1;
+        (void)hipMemcpy(h.any_reset_step, &never, sizeof(never), hipMemcpyHostToDevice);
+    }
     {   // defaults: identity quaternion, unit friction, reset flags = 1 (base_task.py:72)
         float *tmp = new float[(size_t)N * 13]();
         for (int i = 0; i < N; ++i) tmp[(size_t)i * 13 + 6] = 1.0f;
@@ -243,6 +250,19 @@ static int chk_launch() {
     return 0;
 }
 
+// A deferred epilogue (lg_ctx.defer_finalize) that nobody took over runs before anything else touches the env.
+static void flush_finalize(lg_ctx *c) {
+    if (c->finalize_pending) { lgk_finalize(c->d, 1, c->stream); c->finalize_pending = 0; }
+}
+int lg_finalize(lg_ctx *c) { if (!c) return -1; flush_finalize(c); return chk_launch(); }
+// ---- internal (same library, not in the header): the learner's fused rollout epilogue (ppo_api.hip, lg_ppo_attach_env)
+void lg_internal_defer_finalize(lg_ctx *c, int on) { if (!on) flush_finalize(c); c->defer_finalize = on; }
+int lg_internal_finalize_pending(lg_ctx *c) { return c->finalize_pending; }
+// the caller's launch runs the epilogue of the last step: hand over what it needs and clear the flag
+const DevParams *lg_internal_take_finalize(lg_ctx *c, int64_t *counter) { c->finalize_pending = 0; *counter = c->step_counter; return c->d; }
+const DevParams *lg_internal_host_params(lg_ctx *c) { return &c->h; }
+hipStream_t lg_internal_stream(lg_ctx *c) { return c->stream; }
+
 int lg_set_actions(lg_ctx *c, const float *actions) {
     lgk_set_actions(c->d, actions, c->h.cfg.num_envs * c->h.cfg.num_actions, c->stream);
     return chk_launch();
@@ -279,13 +299,16 @@ int lg_set_curriculum_stage(lg_ctx *c, const lg_stage *s, int in_callback) {
     return chk_launch();
 }
 int lg_post_physics_step(lg_ctx *c) {
+    flush_finalize(c);
     c->step_counter += 1;                                       // legged_robot.py:115
     // legged_robot.py:358: common_step_counter % push_time == 0 on the period of the stage in force when the step began
     // (push_time may be fractional after a curriculum multiplier: Python's float modulo)
     const double pt = c->stage.push_time;
     const int push_now = c->h.cfg.push_robots && pt > 0.0 && std::fmod((double)c->step_counter, pt) == 0.0;
     if (c->has_pending) lgk_set_stage(c->d, &c->pending, 1, c->stream);          // what follows the callback sees the new stage
-    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, push_now, c->stream);
+    lgk_post_step(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, push_now, !c->defer_finalize,
+                  c->stream);
+    c->finalize_pending = c->defer_finalize;
     if (c->has_pending) {                                                        // ... and from the next step on the callback too
         lgk_set_stage(c->d, &c->pending, 2, c->stream);
         stage_to_host(c, c->pending);
@@ -294,6 +317,7 @@ int lg_post_physics_step(lg_ctx *c) {
     return chk_launch();
 }
 int lg_reset_all(lg_ctx *c) {
+    flush_finalize(c);
     lgk_reset_all(c->d, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->stream);
     return chk_launch();
 }
@@ -305,6 +329,7 @@ int lg_debug_post_step_cycles(lg_ctx *c, unsigned long long *out /* host, 64 x 8
 int lg_reset_ids(lg_ctx *c, const int32_t *ids, int n) {        // legged_robot.py:147-187
     if (n < 0 || (n > 0 && !ids)) { g_err = "lg_reset_ids: bad id list"; return -1; }
     if (n == 0) return 0;                                       // :156-157
+    flush_finalize(c);
     lgk_reset_ids(c->d, ids, n, c->h.cfg.num_envs, c->step_counter, c->inject, c->init_done, c->h.cfg.traj.enabled, c->stream);
     return chk_launch();
 }
@@ -319,6 +344,7 @@ int lg_debug_set_phys_pair(int v) { lgk_debug_set_phys_pair(v); return 0; }   //
 
 int lg_step(lg_ctx *c, const float *actions) {                  // legged_robot.py:80-104
     int rc;
+    flush_finalize(c);
     if (g_fused_substeps) {                                     // one launch for clip + decimation x {torques, physics}
         rc = run_substeps(c, actions, 3, c->h.cfg.decimation);
     } else {                                                    // launch per substep (A/B and debugging)

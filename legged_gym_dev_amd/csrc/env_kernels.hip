@@ -4,6 +4,7 @@
 #include "lg_device.h"
 #include "lg_physics_pair.h"
 #include "lg_traj.h"
+#include "lg_finalize.h"
 
 // ------------------------------------------------------------------------------------------------
 // LR:86-87  actions = clip(actions, +-clip_actions)
@@ -457,9 +458,6 @@ __device__ float xterm_value(const DevParams *P, int i, const lg_xterm &t, const
     }
     return 0.0f;
 }
-__device__ __forceinline__ float term_scale(const lg_cfg &c, int k) {
-    return k < LG_NUM_REWARDS ? c.rew_scale[k] : (k - LG_NUM_REWARDS < c.num_xterms ? c.xterms[k - LG_NUM_REWARDS].scale : 0.0f);
-}
 
 // reset_traj (LT:222-229) + the stale-trajectory error of LT:199 for one env; root already holds the post-reset pose
 // Inlined into their callers: as separate functions they cost k_post_step a call frame in scratch (saved registers on the
@@ -859,7 +857,7 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     STAMP(3);
     if (s_cnt > 0) {
         if (tid < LG_NUM_TERMS && term_scale(c, tid) != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
-        if (tid == 0) atomicAdd(P->reset_count, s_cnt);
+        if (tid == 0) { atomicAdd(P->reset_count, s_cnt); *P->any_reset_step = counter; }
         if (tid == 0 && s_flt > 0) atomicAdd(P->fault_count, s_flt);
     }
 
@@ -985,54 +983,7 @@ __global__ void k_set_stage(DevParams *P, lg_stage s, int what) {
     }
 }
 
-// Single-workgroup epilogue: extras["episode"], extras["time_outs"] (only refreshed when >=1 env
-// reset this step: the early return of LR:156-157 keeps the previous, stale values), terrain level mean.
-// accumulate = 0 (lg_reset_ids: a reset made outside step()): the per-step logging sums and their step count stay untouched.
-__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P, int64_t counter, int inject, int accumulate) {
-    const lg_cfg &c = P->cfg;
-    const int N = c.num_envs, tid = threadIdx.x;
-    const int n = *P->reset_count;
-    __shared__ float s_red[256];
-    if (n > 0) {
-        if (tid < LG_NUM_TERMS)
-            P->buf.extras_episode[tid] = term_scale(c, tid) != 0.0f ? (P->ep_accum[tid] / (float)n) / c.episode_length_s : 0.0f;
-
-        if (c.send_timeouts) {                       // byte masks, 16 per lane and trip (hipMalloc'ed: 256-byte aligned)
-            const int n16 = N >> 4;
-            for (int i = tid; i < n16; i += 256)
-                reinterpret_cast<uint4 *>(P->buf.extras_time_outs)[i] = reinterpret_cast<const uint4 *>(P->buf.time_out)[i];
-            for (int i = (n16 << 4) + tid; i < N; i += 256) P->buf.extras_time_outs[i] = P->buf.time_out[i];
-        }
-        if (c.curriculum) {
-            float s = 0.0f;
-            for (int i = tid; i < N; i += 256) s += (float)P->buf.terrain_levels[i];
-            s_red[tid] = s;
-            __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if (tid < w) s_red[tid] += s_red[tid + w];
-                __syncthreads();
-            }
-            if (tid == 0) P->buf.extras_terrain_level[0] = s_red[0] / (float)N;
-        }
-    }
-    __syncthreads();
-    if (n > 0 || c.traj.enabled) {
-        const int n16 = N >> 4;
-        for (int i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(P->reset_mark)[i] = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = (n16 << 4) + tid; i < N; i += 256) P->reset_mark[i] = 0;
-    }
-    if (accumulate && tid < LG_NUM_TERMS) P->buf.extras_episode_acc[tid] += P->buf.extras_episode[tid];   // OnPolicyRunner.log: mean over the steps
-    if (tid == 0) {
-        if (accumulate) {
-            P->buf.extras_episode_acc[LG_NUM_TERMS] += P->buf.extras_terrain_level[0];
-            P->buf.extras_episode_acc[LG_NUM_TERMS + 1] += 1.0f;
-        }
-        P->buf.n_reset[0] = n; *P->reset_count = 0;
-        const int nf = *P->fault_count;
-        P->buf.n_fault[0] = nf; P->buf.fault_total[0] += nf; *P->fault_count = 0;
-    }
-    if (tid < LG_NUM_TERMS) P->ep_accum[tid] = 0.0f;
-}
+__global__ void __launch_bounds__(256) k_finalize(const DevParams *__restrict__ P, int accumulate) { finalize_body(P, accumulate); }
 
 // Trajectory env, after the post-step (or lg_reset_ids) and before k_finalize: on a step where some env reset, the reference's
 // generator re-checks the hold time of EVERY env in its reset loop (lg_traj.h, tg_late_resample).  One lane per env.
@@ -1056,7 +1007,7 @@ __global__ void __launch_bounds__(LG_TILE_THREADS) k_reset_ids(const DevParams *
             atomicAdd(P->ep_accum + tid, P->buf.episode_sums[(size_t)tid * N + i]);
             P->buf.episode_sums[(size_t)tid * N + i] = 0.0f;
         }
-        if (tid == 0) atomicAdd(P->reset_count, 1);
+        if (tid == 0) { atomicAdd(P->reset_count, 1); *P->any_reset_step = counter; }
         reset_env_coop(P, i, counter, inject, init_done, s_win);
     }
 }
@@ -1111,11 +1062,16 @@ extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L,
 extern "C" void lgk_set_stage(DevParams *P, const lg_stage *st, int what, hipStream_t s) {
     hipLaunchKernelGGL(k_set_stage, dim3(1), dim3(64), 0, s, P, *st, what);
 }
-extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, int push_now, hipStream_t s) {
+extern "C" void lgk_finalize(const DevParams *P, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, accumulate);
+}
+// finalize = 0: the caller defers the single-workgroup epilogue (lg_ctx.defer_finalize)
+extern "C" void lgk_post_step(const DevParams *P, int N, int64_t counter, int inject, int init_done, int traj, int push_now, int finalize,
+                              hipStream_t s) {
     constexpr int TILE = 16;
     hipLaunchKernelGGL((k_post_step<TILE>), dim3((N + TILE - 1) / TILE), dim3(LG_TILE_THREADS), 0, s, P, counter, inject, init_done, push_now);
     if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject, 1);
+    if (finalize) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, 1);
 }
 extern "C" void lgk_reset_all(const DevParams *P, int N, int64_t counter, int inject, int init_done, hipStream_t s) {
     hipLaunchKernelGGL(k_reset_all, dim3((N + 63) / 64), dim3(64), 0, s, P, counter, inject, init_done);
@@ -1124,5 +1080,5 @@ extern "C" void lgk_reset_ids(const DevParams *P, const int32_t *ids, int n, int
                               hipStream_t s) {
     hipLaunchKernelGGL(k_reset_ids, dim3(n < 1024 ? n : 1024), dim3(LG_TILE_THREADS), 0, s, P, ids, n, counter, inject, init_done);
     if (traj) hipLaunchKernelGGL(k_traj_late, dim3((N + 255) / 256), dim3(256), 0, s, P, counter, inject);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, counter, inject, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, P, 0);
 }

@@ -61,6 +61,8 @@ struct DevParams {
     int32_t *fault_count;          // 1: faults consumed by the running step (block atomics), folded by k_finalize
     uint8_t *fault;                // N: set by the physics fault guard, consumed by the post-step
     uint8_t *reset_mark;           // N: envs reset since the last k_finalize (which clears it)
+    int64_t *any_reset_step;       // 1: step counter of the last step on which at least one env reset (written by every post-step
+                                   // workgroup that resets one; read by the fused rollout epilogue, ppo_mlp_fused.hip)
     unsigned long long *dbg_cycles; // 8 per post-step workgroup (first 64 workgroups): s_memtime at the phase boundaries (tools/post_step_phases.py)
     int K;                         // uniforms per env
     // per-leg sphere tables for the lane-parallel physics: slot-major [slot][leg]
@@ -87,6 +89,8 @@ struct lg_ctx {
     int init_done, inject;
     lg_stage stage, pending;  // curriculum stage in force / to take effect inside the next post-step's callback
     int has_pending;
+    int defer_finalize;       // lg_step leaves its single-workgroup epilogue (k_finalize) to the learner's next act launch
+    int finalize_pending;     // ... and it has not run yet
     void *allocs[128];
     int n_allocs;
 };

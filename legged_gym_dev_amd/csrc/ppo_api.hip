@@ -46,7 +46,14 @@ struct Net {
 };
 
 struct lg_comm;
+struct lg_ctx;
 extern "C" {
+// env side of the fused rollout epilogue (env_api.hip; same library, not in the header)
+void lg_internal_defer_finalize(lg_ctx *c, int on);
+int lg_internal_finalize_pending(lg_ctx *c);
+const DevParams *lg_internal_take_finalize(lg_ctx *c, int64_t *counter);
+const DevParams *lg_internal_host_params(lg_ctx *c);
+int lg_finalize(lg_ctx *c);
 hipStream_t lg_comm_stream_(lg_comm *c);
 hipEvent_t lg_comm_event_(lg_comm *c);
 int lg_comm_group_allreduce_(lg_comm *c, float *const *bufs, const int64_t *counts, int n, hipStream_t s);
@@ -67,6 +74,9 @@ struct lg_ppo {
     int overlap;
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;
+    // fused rollout epilogue (lg_ppo_attach_env): a process_env_step recorded for the next act launch
+    lg_ctx *env;
+    int pp_pending, pp_t, pp_use_tos;
     int params_dirty;                        // the fp32 parameters changed since the rollout images (fragment-order weights / bf16 planes)
                                              // were derived from them: optimiser step, broadcast, lg_ppo_params_changed()
     int fused_act;                           // rollout forward through k_mlp_fwd when the network shape allows (else per-layer GEMMs)
@@ -232,10 +242,23 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
     }
 }
 
+// What a deferred process_env_step (and the env's epilogue before it) still owes, the ordinary way: env epilogue first, then the
+// process kernel on the refreshed extras["time_outs"] -- the order of the unfused loop.
+static void flush_rollout_epilogue(lg_ppo *p) {
+    if (!p->env) return;
+    (void)lg_finalize(p->env);
+    if (p->pp_pending) {
+        const lg_buffers &b = lg_internal_host_params(p->env)->buf;
+        ppok_process_step(&p->dev, b.rew, b.reset, p->pp_use_tos ? b.extras_time_outs : nullptr, p->pp_t, p->stream);
+        p->pp_pending = 0;
+    }
+}
+
 extern "C" {
 
 int lg_ppo_destroy(lg_ppo *p) {
     if (!p) return 0;
+    if (p->env) { flush_rollout_epilogue(p); lg_internal_defer_finalize(p->env, 0); p->env = nullptr; }
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
     if (p->ev_dz) (void)hipEventDestroy(p->ev_dz);
     if (p->ev_side) (void)hipEventDestroy(p->ev_side);
@@ -249,7 +272,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     if (!cfg || !out) { lg_set_error("null argument"); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { lg_set_error("no HIP device: no CPU fallback"); return -2; }
-    if (cfg->activation < 0 || cfg->activation > 5) { lg_set_error("activation must be one of elu, selu, relu, lrelu, tanh, sigmoid (crelu changes the layer widths and is not implemented)"); return -3; }
+    if (cfg->activation < 0 || cfg->activation > 5) { lg_set_error("activation must be one of 0 elu, 1 selu, 2 relu (also rsl_rl's crelu), 3 lrelu, 4 tanh, 5 sigmoid"); return -3; }
     if (cfg->num_hidden < 1 || cfg->num_hidden > LG_MAX_HIDDEN || cfg->num_actions > LG_PPO_MAX_A) {
         lg_set_error("unsupported network size"); return -4;
     }
@@ -270,6 +293,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     }
     p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0; p->params_dirty = 1;
     p->comm = nullptr; p->comm_rc = 0;
+    p->env = nullptr; p->pp_pending = 0;
     if (getenv("LG_XCD_REMAP")) ppok_debug_set_xcd_remap(atoi(getenv("LG_XCD_REMAP")));
     if (getenv("LG_DW_T")) ppok_debug_set_dw_t(atoi(getenv("LG_DW_T")));
     p->perm_count = 0;
@@ -421,6 +445,18 @@ int lg_ppo_param_layout(lg_ppo *p, int64_t *offsets, int64_t *shapes, int max_en
     return k;
 }
 
+int lg_ppo_attach_env(lg_ppo *p, lg_ctx *env) {
+    flush_rollout_epilogue(p);
+    if (p->env) lg_internal_defer_finalize(p->env, 0);
+    p->env = nullptr;
+    if (env) {
+        if (lg_internal_host_params(env)->cfg.num_envs != p->cfg.num_envs) { lg_set_error("lg_ppo_attach_env: env and learner differ in num_envs"); return -12; }
+        p->env = env;
+        lg_internal_defer_finalize(env, 1);
+    }
+    return launch_ok();
+}
+
 int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
     if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
     const float *cobs = critic_obs ? critic_obs : obs;
@@ -436,9 +472,20 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
         if (dirty) ppok_mlp_frag_build(&g, p->stream);
         static const int fuse_sample = getenv("LG_FUSED_SAMPLE") ? atoi(getenv("LG_FUSED_SAMPLE")) : 1;
         g.sample = fuse_sample; g.t = p->step; g.inject = p->inject; g.act_count = p->act_count;
+        g.pp = 0;
+        const int N = p->cfg.num_envs;
+        const bool fits = (N + 255) / 256 + 1 <= (N + 31) / 32;  // epilogue workgroups within the launch's grid.x
+        if (p->env && p->pp_pending && g.sample && fits) {        // the previous step's epilogue rides on this launch
+            g.pp = lg_internal_finalize_pending(p->env) ? 2 : 1;
+            g.pp_t = p->pp_t; g.pp_use_tos = p->pp_use_tos;
+            g.pp_env = lg_internal_take_finalize(p->env, &g.pp_counter);
+            p->pp_pending = 0;
+        } else flush_rollout_epilogue(p);
         fused = ppok_mlp_fwd(&g, &p->dev, 3, p->stream);
+        if (fused != 0 && g.pp) { lg_set_error("fused act launch refused with a rollout epilogue attached"); return -13; }
         if (fused == 0 && g.sample) { p->act_count++; return launch_ok(); }       // sampled and stored by the same launch
     }
+    if (!p->fused_act) flush_rollout_epilogue(p);
     if (fused != 0) {
         // per-layer GEMMs on the optimiser's weight planes (no re-split of W per tile); same freshness rule as above
         static const int act_planes = getenv("LG_ACT_PLANES") ? atoi(getenv("LG_ACT_PLANES")) : 1;
@@ -453,12 +500,23 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
 
 int lg_ppo_process_env_step(lg_ppo *p, const float *rew, const uint8_t *dones, const uint8_t *time_outs) {
     if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
+    if (p->env) {
+        // attached env: when the arguments are that env's own step outputs, record the call for the next act launch
+        const lg_buffers &b = lg_internal_host_params(p->env)->buf;
+        if (p->fused_act && !p->pp_pending && rew == b.rew && dones == b.reset && (!time_outs || time_outs == b.extras_time_outs)) {
+            p->pp_pending = 1; p->pp_t = p->step; p->pp_use_tos = time_outs != nullptr;
+            p->step++;
+            return 0;
+        }
+        flush_rollout_epilogue(p);
+    }
     ppok_process_step(&p->dev, rew, dones, time_outs, p->step, p->stream);
     p->step++;
     return launch_ok();
 }
 
 int lg_ppo_compute_returns(lg_ppo *p, const float *last_critic_obs) {
+    flush_rollout_epilogue(p);
     forward(p, p->cfg.num_envs, nullptr, last_critic_obs, 2);
     ppok_gae(&p->dev, p->net[1].act[p->net[1].nl], p->stream);
     return launch_ok();
@@ -470,6 +528,7 @@ int lg_ppo_normalize_advantages(lg_ppo *p) {
 }
 
 int lg_ppo_begin_update(lg_ppo *p) {
+    flush_rollout_epilogue(p);
     // randperm(num_mini_batches * mini_batch_size), drawn once per update and reused by every epoch (Appendix B): on the device
     const size_t n = (size_t)p->dev.mb_rows * p->cfg.num_mini_batches;
     ppok_randperm(&p->dev, (int)n, (uint64_t)p->perm_count++, p->stream);

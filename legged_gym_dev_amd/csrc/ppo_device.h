@@ -54,6 +54,29 @@ struct PpoDev {                    // passed by value to kernels
     int seg_rows[LG_PPO_MAX_SEG], seg_cols[LG_PPO_MAX_SEG];
 };
 
+// PPO.process_env_step for env i at rollout step t: rewards += gamma * V * time_outs ; store ; runner bookkeeping
+// (OnPolicyRunner.learn: cur_reward_sum / cur_episode_length / rewbuffer).  to: the env's extras["time_outs"] entry, or false.
+__device__ __forceinline__ void process_step_body(const PpoDev &P, float rew, bool done, bool to, int t, int i) {
+    float r = rew;
+    r += P.gamma * (P.st_values[(size_t)t * P.N + i] * (to ? 1.0f : 0.0f));
+    P.st_rewards[(size_t)t * P.N + i] = r;
+    P.st_dones[(size_t)t * P.N + i] = done ? 1 : 0;
+    const float cr = P.cur_reward_sum[i] + rew, cl = P.cur_episode_len[i] + 1.0f;
+    if (done) {
+        atomicAdd(&P.ep_stats[0], cr);
+        atomicAdd(&P.ep_stats[1], cl);
+        atomicAdd(&P.ep_stats[2], 1.0f);
+        const int slot = (int)((unsigned)atomicAdd(P.ep_ring_count, 1) % 100u);   // rewbuffer / lenbuffer = deque(maxlen=100)
+        P.ep_ring[slot] = cr;
+        P.ep_ring[100 + slot] = cl;
+        P.cur_reward_sum[i] = 0.f;
+        P.cur_episode_len[i] = 0.f;
+    } else {
+        P.cur_reward_sum[i] = cr;
+        P.cur_episode_len[i] = cl;
+    }
+}
+
 // standard normal of (seed, env, act() call, action index): Box-Muller on one Philox4x32-10 block (k_act_sample, k_mlp_fwd)
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t env, uint64_t step, uint32_t a) {
     uint32_t c[4] = {env, (uint32_t)step, a, 0x5eedu};

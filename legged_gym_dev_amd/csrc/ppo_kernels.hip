@@ -938,25 +938,7 @@ __global__ void k_process_step(PpoDev P, const float *__restrict__ rew, const ui
                                const uint8_t *__restrict__ time_outs, int t) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.N) return;
-    float r = rew[i];
-    if (time_outs) r += P.gamma * (P.st_values[(size_t)t * P.N + i] * (time_outs[i] ? 1.0f : 0.0f));
-    P.st_rewards[(size_t)t * P.N + i] = r;
-    P.st_dones[(size_t)t * P.N + i] = dones[i] ? 1 : 0;
-    // runner bookkeeping (OnPolicyRunner.learn: cur_reward_sum / cur_episode_length / rewbuffer)
-    const float cr = P.cur_reward_sum[i] + rew[i], cl = P.cur_episode_len[i] + 1.0f;
-    if (dones[i]) {
-        atomicAdd(&P.ep_stats[0], cr);
-        atomicAdd(&P.ep_stats[1], cl);
-        atomicAdd(&P.ep_stats[2], 1.0f);
-        const int slot = (int)((unsigned)atomicAdd(P.ep_ring_count, 1) % 100u);   // rewbuffer / lenbuffer = deque(maxlen=100)
-        P.ep_ring[slot] = cr;
-        P.ep_ring[100 + slot] = cl;
-        P.cur_reward_sum[i] = 0.f;
-        P.cur_episode_len[i] = 0.f;
-    } else {
-        P.cur_reward_sum[i] = cr;
-        P.cur_episode_len[i] = cl;
-    }
+    process_step_body(P, rew[i], dones[i] != 0, time_outs && time_outs[i], t, i);
 }
 
 // RolloutStorage.compute_returns: GAE reverse scan, one lane per env; block sums of adv, adv^2

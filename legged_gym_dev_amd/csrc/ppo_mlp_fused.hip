@@ -11,6 +11,7 @@
 // result back to LDS for the next layer; only the head outputs (means, value) go to HBM.
 #include "ppo_device.h"
 #include "ppo_mlp_args.h"
+#include "lg_finalize.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -195,7 +196,27 @@ __global__ void __launch_bounds__(256) k_mlp_frag_build(MlpArgs g, uint16_t *__r
         }
 }
 
+// The previous policy step's epilogue, on workgroups beside the two MLPs (MlpArgs::pp).  Step s ran k_post_step; what follows it --
+// the env's extras / counters and the learner's process_env_step -- depends on nothing this act computes and nothing here feeds
+// the MLPs, so it shares the launch.  extras["time_outs"] is the reference's stale mask (legged_robot.py:156-157,186-187: refreshed
+// only on a step with at least one reset): the env epilogue refreshes it exactly when any_reset_step == the step's counter, and in
+// that case the process lanes read the fresh time_out mask instead, so they never read what the epilogue workgroup is writing.
+__device__ __forceinline__ void rollout_epilogue(const MlpArgs &g, const PpoDev &P) {
+    const DevParams *E = g.pp_env;
+    const int nproc = (P.N + MLP_NT - 1) / MLP_NT;
+    if ((int)blockIdx.x < nproc) {
+        const int i = blockIdx.x * MLP_NT + threadIdx.x;
+        if (i >= P.N) return;
+        const bool fresh = *E->any_reset_step == g.pp_counter;
+        const bool to = g.pp_use_tos && (fresh ? E->buf.time_out[i] : E->buf.extras_time_outs[i]) != 0;
+        process_step_body(P, E->buf.rew[i], E->buf.reset[i] != 0, to, g.pp_t, i);
+    } else if ((int)blockIdx.x == nproc && g.pp == 2) {
+        finalize_body(E, 1);
+    }
+}
+
 __global__ void __launch_bounds__(MLP_NT, 1) k_mlp_fwd(MlpArgs g, PpoDev P) {
+    if (blockIdx.y == 2) { rollout_epilogue(g, P); return; }
     const int z = blockIdx.y;
     const int row0 = blockIdx.x * MLP_ROWS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
@@ -294,7 +315,9 @@ extern "C" void ppok_mlp_frag_build(const MlpArgs *g, hipStream_t s) {
 extern "C" int ppok_mlp_fwd(const MlpArgs *g, const PpoDev *P, int mask, hipStream_t s) {
     if (mask != 3 || ppok_mlp_supported(g) || ((uintptr_t)g->wfrag & 15)) return -1;
     if (g->sample && (g->M != P->N || g->dims[0][g->nl] != P->A || g->dims[1][g->nl] != 1 || P->A > LG_PPO_MAX_A)) return -1;
-    dim3 grid((g->M + MLP_ROWS - 1) / MLP_ROWS, 2);
+    static_assert(MLP_NT == 256, "finalize_body and the process lanes are written for 256 threads");
+    if (g->pp && (P->N + MLP_NT - 1) / MLP_NT + 1 > (g->M + MLP_ROWS - 1) / MLP_ROWS) return -1;   // epilogue blocks must fit grid.x
+    dim3 grid((g->M + MLP_ROWS - 1) / MLP_ROWS, g->pp ? 3 : 2);
     hipLaunchKernelGGL(k_mlp_fwd, grid, dim3(MLP_NT), 0, s, *g, *P);
     return 0;
 }

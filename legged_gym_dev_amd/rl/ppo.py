@@ -18,7 +18,9 @@ def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-_ACTIVATIONS = {"elu": 0, "selu": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}
+# rsl_rl v1.0.2 get_activation (rsl_rl/modules/actor_critic.py, third-party -- recalled, not in the reference tree): its "crelu"
+# entry returns nn.ReLU(), so the name listed at legged_robot_config.py:244 is plain ReLU with unchanged layer widths
+_ACTIVATIONS = {"elu": 0, "selu": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5, "crelu": 2}
 
 
 class HipPPO:
@@ -34,8 +36,7 @@ class HipPPO:
             raise ValueError("actor/critic need the same number (<=4) of hidden layers")
         self.activation = policy_cfg.get("activation", "elu")
         if self.activation not in _ACTIVATIONS:
-            raise NotImplementedError(f"activation {self.activation!r}: HIP epilogues exist for {sorted(_ACTIVATIONS)} "
-                                      "(crelu doubles the layer widths and is not implemented)")
+            raise NotImplementedError(f"activation {self.activation!r}: HIP epilogues exist for {sorted(_ACTIVATIONS)}")
         c = capi.lg_ppo_cfg()
         c.num_envs, c.num_obs, c.num_actions = num_envs, num_obs, num_actions
         self.privileged = num_critic_obs is not None and num_critic_obs != num_obs
@@ -172,6 +173,10 @@ class HipPPO:
         for k, v in sd.items():
             self.param_views[k].copy_(v.to(self.device))
         self.params_changed()
+
+    def attach_env(self, core):
+        """lg_ppo_attach_env: ``core`` = the env's HipEnvCore (or None to detach, which runs whatever is still pending)."""
+        self._call("attach_env", core.ctx if core is not None else None)
 
     def params_changed(self):
         """Call after writing parameters through ``param_views`` / ``t["params"]``: the rollout's weight images are re-derived

@@ -101,6 +101,7 @@ class OnPolicyRunner:
             self.ppo.params_changed()
             if hasattr(self.comm, "attach"):
                 self.comm.attach(self.ppo)            # NativeComm: gradients reduced inside the backward pass from here on
+        self.fuse_epilogue = os.environ.get("LG_FUSE_EPILOGUE", "1") != "0"
         self.log_dir = log_dir
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.rewbuffer, self.lenbuffer = deque(maxlen=100), deque(maxlen=100)
@@ -119,14 +120,24 @@ class OnPolicyRunner:
 
     # ------------------------------------------------------------------
     def rollout(self):
+        """24 x {act, env.step, process_env_step} + compute_returns.  For the duration of the rollout the env is attached to the
+        learner (lg_ppo_attach_env): the step's single-workgroup epilogue and process_env_step ride on the next act's launch --
+        3 launches per policy step instead of 5, same results (LG_FUSE_EPILOGUE=0 keeps them as launches of their own)."""
         env, ppo = self.env, self.ppo
         obs = env.get_observations()
-        for _ in range(self.num_steps_per_env):
-            actions = ppo.act(obs, None)
-            obs, priv, rewards, dones, infos = env.step(actions)
-            ppo.process_env_step(rewards, env.core.t["reset"], {"time_outs": env.core.t["extras_time_outs"]}
-                                 if "time_outs" in infos else {})
-        ppo.compute_returns(obs, self._all_reduce if self.world_size > 1 else None)
+        fuse = self.fuse_epilogue
+        if fuse:
+            ppo.attach_env(env.core)
+        try:
+            for _ in range(self.num_steps_per_env):
+                actions = ppo.act(obs, None)
+                obs, priv, rewards, dones, infos = env.step(actions)
+                ppo.process_env_step(rewards, env.core.t["reset"], {"time_outs": env.core.t["extras_time_outs"]}
+                                     if "time_outs" in infos else {})
+            ppo.compute_returns(obs, self._all_reduce if self.world_size > 1 else None)
+        finally:
+            if fuse:
+                ppo.attach_env(None)
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         env, ppo = self.env, self.ppo

@@ -18,7 +18,7 @@ class ActorCritic(nn.Module):
                  critic_hidden_dims=(256, 256, 256), activation="elu", init_noise_std=1.0):
         super().__init__()
         act = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh,
-               "sigmoid": nn.Sigmoid}[activation]                # rsl_rl get_activation (crelu not covered)
+               "sigmoid": nn.Sigmoid, "crelu": nn.ReLU}[activation]   # rsl_rl get_activation ("crelu" returns nn.ReLU() there)
 
         def mlp(i, hidden, o):
             layers, d = [], i

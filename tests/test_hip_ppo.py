@@ -359,9 +359,9 @@ def test_weight_plane_gemms_are_fp32_accurate(mode, M, rows, cols):
     assert err_pl <= 2.0 * err_f32 + 2.0 ** -22 * float(ref.abs().max()), (err_pl, err_f32)
 
 
-@pytest.mark.parametrize("activation", ["selu", "relu", "lrelu", "tanh", "sigmoid"])
+@pytest.mark.parametrize("activation", ["selu", "relu", "lrelu", "tanh", "sigmoid", "crelu"])
 def test_other_activations_forward_and_gradients(activation):
-    """ActorCritic `activation` values other than elu (legged_robot_config.py:244; crelu excluded): inference
+    """ActorCritic `activation` values other than elu (legged_robot_config.py:244; rsl_rl's "crelu" is nn.ReLU): inference
     means and one minibatch's gradients (GEMM epilogues act / act' computed from the stored outputs) against
     autograd on the torch restatement.  Tolerances as for elu: 2e-4 on means, 2e-3 relative / 2e-4 of the
     gradient scale absolute on gradients."""

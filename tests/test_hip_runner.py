@@ -152,3 +152,58 @@ def test_sizes_off_every_tile_grid(case):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import size_sweep
     size_sweep.run(*case)
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough", "anymal_c_flat_trajectory"])
+def test_fused_rollout_epilogue_equals_separate_launches(task):
+    """OnPolicyRunner.rollout with the env attached to the learner (lg_ppo_attach_env: the step's single-workgroup epilogue and
+    process_env_step ride on the next act's launch) against the same rollout with every piece as a launch of its own: rollout
+    storage (observations, actions, values, log-probs, rewards incl. the time-out bootstrap on the reference's stale mask, dones),
+    the runner's episode bookkeeping, the env's extras / logging sums and its state must come out bit for bit the same.  Episode
+    clocks are scattered so that time-outs (and steps without any reset, where the stale mask is what counts) both occur."""
+    import copy
+    from legged_gym_dev_amd.envs import task_registry
+    from legged_gym_dev_amd.rl.runner import OnPolicyRunner
+    from legged_gym_dev_amd.utils.helpers import class_to_dict
+    outs = []
+    for fuse in (True, False):
+        args = _args(task, 256)
+        env_cfg, train_cfg = (copy.deepcopy(c) for c in task_registry.get_cfgs(task))
+        env_cfg.env.num_envs = 256
+        if env_cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            env_cfg.terrain.num_rows, env_cfg.terrain.num_cols, env_cfg.terrain.border_size = 4, 8, 5
+            env_cfg.terrain.max_init_terrain_level = 3
+        train_cfg.policy.actor_hidden_dims = train_cfg.policy.critic_hidden_dims = [128, 64, 32]
+        env, _ = task_registry.make_env(name=task, args=args, env_cfg=env_cfg)
+        torch.manual_seed(7)
+        runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device="cuda:0")
+        runner.fuse_epilogue = fuse
+        try:
+            assert runner.ppo.lib.lg_ppo_debug_get_fused_act(runner.ppo.ctx) == 1
+            ep = torch.arange(256, device="cuda:0") * 4 % 1001
+            ep[:6] = torch.tensor([1000, 1001, 999, 990, 985, 980], device="cuda:0")
+            env.episode_length_buf = ep
+            rec = {}
+            for it in range(2):
+                runner.rollout()
+                torch.cuda.synchronize()
+                for k in ("obs", "actions", "values", "log_prob", "rewards", "dones", "mu", "returns", "advantages", "cur_reward_sum",
+                          "cur_episode_len", "ep_stats", "ep_ring", "ep_ring_count"):
+                    rec[f"{it}_{k}"] = runner.ppo.t[k].clone()
+                for k in ("extras_episode", "extras_time_outs", "extras_episode_acc", "n_reset", "root_states", "dof_state", "episode_length",
+                          "episode_sums", "obs", "rew", "reset"):
+                    rec[f"{it}_env_{k}"] = env.core.t[k].clone()
+                runner.ppo._call("end_update")                   # rewind the storage cursor (no update: same policy in both runs)
+            assert int(rec["1_ep_ring_count"]) > 5 and bool(rec["1_dones"].any())
+            outs.append(rec)
+        finally:
+            env.close()
+            runner.ppo.close()
+    a, b = outs
+    for k in a:
+        if k.endswith("ep_ring"):            # slot order inside one step follows the atomics; compare as multisets
+            assert torch.equal(a[k].sort(dim=1).values, b[k].sort(dim=1).values), k
+        elif k.endswith("ep_stats") or k.endswith("adv_partial"):
+            torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-5, msg=k)
+        else:
+            assert torch.equal(a[k], b[k]), k
