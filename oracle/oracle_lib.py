@@ -12,11 +12,13 @@ import numpy as np
 from legged_gym_dev_amd import capi
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_DIR, "_build", "liblegged_oracle.so")
+_SO = os.environ.get("LG_ORACLE_LIB") or os.path.join(_DIR, "_build", "liblegged_oracle.so")   # LG_ORACLE_LIB: `make -C oracle san`
 _lib = None
 
 
 def build(force=False):
+    if os.environ.get("LG_ORACLE_LIB"):
+        return _SO
     srcs = [os.path.join(_DIR, f) for f in ("lgo_env.cpp", "lgo_traj.cpp", "lgo_physics.cpp", "lgo_api.cpp", "lgo_common.h")]
     srcs.append(os.path.join(os.path.dirname(_DIR), "include", "legged_hip.h"))
     if (not force and os.path.isfile(_SO)
