@@ -166,9 +166,11 @@ typedef struct lg_cfg {
     int32_t terrain_type /*0 plane, 1 height samples*/, curriculum, custom_origins, max_terrain_level;
     int32_t hf_rows, hf_cols, terrain_num_cols, phys_substeps;
     int32_t env_offset, total_envs;       /* this shard's first global env id / envs over all ranks */
-    int32_t solver_iterations, _pad1;
+    int32_t solver_iterations;
+    int32_t material_rand;                /* lg_buffers.material holds per-env restitution / compliance / thickness draws (else unread) */
     uint64_t seed;
-    float sim_dt, dt, action_scale, clip_actions, clip_obs, max_push_vel, episode_length_s, _pad2;
+    float sim_dt, dt, action_scale, clip_actions, clip_obs, max_push_vel, episode_length_s;
+    float ground_restitution;             /* terrain.restitution; combined with the env's by averaging, like friction */
     float cmd_lo[4], cmd_hi[4];           /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading */
     float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
     float tracking_sigma, soft_dof_vel_limit, soft_torque_limit, base_height_target, max_contact_force;
@@ -179,7 +181,8 @@ typedef struct lg_cfg {
     float dof_pos_limits[LG_MAX_DOF][2];  /* soft limits (legged_robot.py:313-327) */
     float dof_vel_limits[LG_MAX_DOF], torque_limits[LG_MAX_DOF];
     float gravity[3], ground_friction;    /* ground mu; combined with the env's mu by averaging */
-    float contact_offset, max_depenetration_velocity, contact_erp, _pad3;
+    float contact_offset, max_depenetration_velocity, contact_erp;
+    float bounce_threshold;               /* sim.physx.bounce_threshold_velocity: approach speeds below it do not bounce */
     int32_t num_xterms, feet_air_time_ungated /* trajectory env: no command gate (legged_robot_trajectory.py:1071-1080) */;
     int32_t num_terms, _pad4;
     int32_t term_order[LG_NUM_TERMS];   /* active terms (builtin id, or LG_NUM_REWARDS + xterm index) in the order the

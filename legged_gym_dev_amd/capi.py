@@ -83,10 +83,10 @@ class lg_cfg(C.Structure):
         ("add_noise", i32), ("measure_heights", i32), ("only_positive_rewards", i32), ("send_timeouts", i32),
         ("terrain_type", i32), ("curriculum", i32), ("custom_origins", i32), ("max_terrain_level", i32),
         ("hf_rows", i32), ("hf_cols", i32), ("terrain_num_cols", i32), ("phys_substeps", i32),
-        ("env_offset", i32), ("total_envs", i32), ("solver_iterations", i32), ("_pad1", i32),
+        ("env_offset", i32), ("total_envs", i32), ("solver_iterations", i32), ("material_rand", i32),
         ("seed", u64),
         ("sim_dt", f32), ("dt", f32), ("action_scale", f32), ("clip_actions", f32), ("clip_obs", f32),
-        ("max_push_vel", f32), ("episode_length_s", f32), ("_pad2", f32),
+        ("max_push_vel", f32), ("episode_length_s", f32), ("ground_restitution", f32),
         ("cmd_lo", f32 * 4), ("cmd_hi", f32 * 4),
         ("obs_scale_lin_vel", f32), ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32),
         ("obs_scale_dof_vel", f32), ("obs_scale_height", f32),
@@ -97,7 +97,7 @@ class lg_cfg(C.Structure):
         ("default_dof_pos", f32 * MAX_DOF), ("p_gains", f32 * MAX_DOF), ("d_gains", f32 * MAX_DOF),
         ("dof_pos_limits", f32 * 2 * MAX_DOF), ("dof_vel_limits", f32 * MAX_DOF), ("torque_limits", f32 * MAX_DOF),
         ("gravity", f32 * 3), ("ground_friction", f32),
-        ("contact_offset", f32), ("max_depenetration_velocity", f32), ("contact_erp", f32), ("_pad3", f32),
+        ("contact_offset", f32), ("max_depenetration_velocity", f32), ("contact_erp", f32), ("bounce_threshold", f32),
         ("num_xterms", i32), ("feet_air_time_ungated", i32), ("num_terms", i32), ("_pad4", i32),
         ("term_order", i32 * NUM_TERMS), ("xterms", lg_xterm * MAX_XTERMS), ("traj", lg_traj_cfg),
         ("lstm_w", f32 * LSTM_NW),

@@ -142,6 +142,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
     __shared__ __attribute__((aligned(16))) float s_w[LSTM ? LG_LSTM_LDS : 4];
     __shared__ float s_act[ROWS], s_q[ROWS], s_qd[ROWS], s_tau[ROWS];
     __shared__ float s_cf[EPW * LG_MAX_BODIES * 3];          // net contact force per (env, body) of the last control substep
+    __shared__ float s_mat[EPW * 4];                         // per-env shape material (restitution, compliance, thickness): read only
+    if (c.material_rand)                                     // when the cfg randomises them (lg_cfg.material_rand)
+        for (int t = tid; t < EPW * 4; t += NT) s_mat[t] = P->buf.material[(size_t)min(env0 + t / 4, N - 1) * 4 + (t & 3)];
     for (int t = tid; t < EPW * LG_MAX_BODIES * 3; t += NT) s_cf[t] = 0.f;
     for (int t = tid; t < L * LG_LT_STRIDE; t += NT) s_lt[t] = (&P->leg_tab[0][0])[t];
     if (LSTM)
@@ -241,11 +244,11 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
                 bool fault;
                 V3 fb;
                 if constexpr (PAIR) {
-                    fault = physics_pair<L, J>(P, leg, hrole, tid >> 1, tid, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk,
+                    fault = physics_pair<L, J>(P, leg, hrole, tid >> 1, tid, dt, root, q, qd, tau, fr, dm, s_mat + 4 * pe, fslot, fbase, s_ct, s_lk,
                                                s_lk + J * LG_LKP_NF * 64, s_lt, s_lm, pr);
                     fb = pleg_sum<L>(fbase);
                 } else {
-                    fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
+                    fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, s_mat + 4 * pe, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
                     fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
                 }
                 if (fault && live && leg == 0 && writer) P->fault[env] = 1;

@@ -158,6 +158,7 @@ __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
 template <int L, int J>
 __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
                                              float *qd, const float *tau, float friction, float dmass,
+                                             const float *__restrict__ mat /* LDS: this env's restitution, compliance, thickness */,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt,
                                              const float *__restrict__ ltab, float *__restrict__ lmt) {
     const lg_cfg &c = P->cfg;
@@ -312,6 +313,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             V3 cw = xw + mul(Rb, cbk);
             Ground g = ground_at(P, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
+            if (c.material_rand) gap -= mat[2];                 // shape thickness: the robot rests that far off the surface
             if (gap < c.contact_offset) {
                 active = true;
                 nb = mulT(Rb, g.n);
@@ -362,6 +364,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
         }
         if (valid) {
+            if (c.material_rand) Wc[0][0] += mat[1] * inv_dt * inv_dt;      // compliance (m/N) as constraint-force mixing on the normal row
             CF(si, 6) = Wc[0][0] > 1e-9f ? frcp(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
             CF(si, 9) = Wc[1][1] > 1e-9f ? frcp(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
             CF(si, 11) = Wc[2][2] > 1e-9f ? frcp(Wc[2][2]) : 0.f;
@@ -438,6 +441,8 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                     tangents(nb, t1, t2);
                     V3 vP = vl.v + cross(vl.w, Pc);
                     float vc0 = dot(nb, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
+                    if (c.material_rand && it == 0 && vc0 < -c.bounce_threshold)      // restitution: leave with e x the approach speed
+                        CF(si, 12) = fmaxf(CF(si, 12), -0.5f * (mat[0] + c.ground_restitution) * vc0);
                     float ln = fmaxf(0.0f, oln - relax * (vc0 - CF(si, 12)) * CF(si, 6));
                     float dn = ln - oln;
                     vc1 += CF(si, 7) * dn;

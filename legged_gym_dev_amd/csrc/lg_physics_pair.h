@@ -139,6 +139,7 @@ struct SubProf {};
 template <int L, int J>
 __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, int leg, bool h, int pcol, int lcol, float dt,
                                              float *root, float *q, float *qd, const float *tau, float friction, float dmass,
+                                             const float *__restrict__ mat /* LDS: this env's restitution, compliance, thickness */,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkp,
                                              float *__restrict__ lkh, const float *__restrict__ ltab, float *__restrict__ lmt,
                                              SubProf &pr) {
@@ -300,6 +301,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
             V3 cw = xw + mul(Rb, cbk);
             Ground g = ground_at(P, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
+            if (c.material_rand) gap -= mat[2];                 // shape thickness: the robot rests that far off the surface
             if (gap < c.contact_offset) {
                 active = true;
                 nb = mulT(Rb, g.n);
@@ -350,6 +352,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
         }
         if (valid) {
             CF(si, 16) = t1.x; CF(si, 17) = t1.y; CF(si, 18) = t1.z;   // first tangent: the sweeps and the force output rebuild t2 = n x t1 only
+            if (c.material_rand) Wc[0][0] += mat[1] * inv_dt * inv_dt;      // compliance (m/N) as constraint-force mixing on the normal row
             CF(si, 6) = Wc[0][0] > 1e-9f ? frcp(Wc[0][0]) : 0.f; CF(si, 7) = Wc[1][0]; CF(si, 8) = Wc[2][0];
             CF(si, 9) = Wc[1][1] > 1e-9f ? frcp(Wc[1][1]) : 0.f; CF(si, 10) = Wc[2][1];
             CF(si, 11) = Wc[2][2] > 1e-9f ? frcp(Wc[2][2]) : 0.f;
@@ -428,6 +431,8 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
                     const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
                     const V3 t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}, t2 = cross(nb, t1);
                     float vc0 = dot(nb, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
+                    if (c.material_rand && it == 0 && vc0 < -c.bounce_threshold)      // restitution: leave with e x the approach speed
+                        CF(si, 12) = fmaxf(CF(si, 12), -0.5f * (mat[0] + c.ground_restitution) * vc0);
                     float ln = fmaxf(0.0f, oln - relax * (vc0 - CF(si, 12)) * CF(si, 6));
                     float dn = ln - oln;
                     vc1 += CF(si, 7) * dn;

@@ -411,6 +411,11 @@ class EnvSetup:
         c.contact_offset = float(getattr(physx, "contact_offset", 0.01))
         c.max_depenetration_velocity = float(getattr(physx, "max_depenetration_velocity", 1.0))
         c.contact_erp = 0.2
+        c.bounce_threshold = float(getattr(physx, "bounce_threshold_velocity", 0.5))
+        c.ground_restitution = float(getattr(cfg.terrain, "restitution", 0.0))
+        rsp = getattr(cfg.domain_rand, "rigid_shape_properties", None)
+        c.material_rand = int(bool(cfg.domain_rand.randomize_friction) and rsp is not None and any(
+            getattr(rsp, "randomize_" + k, False) for k in ("restitution", "compliance", "thickness")))
         if self.use_actuator_net:
             w = load_actuator_weights(getattr(cfg.control, "actuator_net_file", ""))
             C.memmove(c.lstm_w, w.ctypes.data, w.nbytes)

@@ -238,12 +238,14 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     int nc = 0;
     int group_count[LG_MAX_DOF + 1] = {};
     const float mu = 0.5f * (e.friction[i] + c.ground_friction);
+    const float *mat = &e.material[(size_t)i * 4];                       // restitution, compliance, thickness (lg_cfg.material_rand)
     for (int k = 0; k < m.num_spheres; ++k) {
         int l = m.sph_link[k] + 1;
         V3 cbk = p[l] + mul(R[l], V3{m.sph_center[k][0], m.sph_center[k][1], m.sph_center[k][2]});
         V3 cw = xw + mul(Rb, cbk);
         Ground g = ground_at(e, cw.x, cw.y);
         float gap = (cw.z - g.h) * g.n.z - m.sph_radius[k];
+        if (c.material_rand) gap -= mat[2];                              // shape thickness: the robot rests that far off the surface
         if (gap >= c.contact_offset) continue;
         Contact &C = ct[nc++];
         C.link = l;
@@ -269,6 +271,7 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
             V3 dvP = dv[l].v + cross(dv[l].w, C.P);
             for (int b = 0; b < 3; ++b) C.W[b][a] = dot(dirs[b], dvP);
         }
+        if (c.material_rand) C.W[0][0] += mat[1] * (1.0f / dt) * (1.0f / dt);   // compliance (m/N) as constraint-force mixing on the normal row
         for (int a = 0; a < 3; ++a) C.iW[a] = C.W[a][a] > 1e-9f ? 1.0f / C.W[a][a] : 0.0f;
     }
     for (int k = 0; k < nc; ++k) ct[k].relax = 1.0f / (float)group_count[ct[k].group];
@@ -319,6 +322,8 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
             V3 vP = velf[C.link].v + cross(velf[C.link].w, C.P);
             float vc[3] = {dot(C.n, vP), dot(C.t1, vP), dot(C.t2, vP)};
             float old[3] = {C.lam[0], C.lam[1], C.lam[2]};
+            if (c.material_rand && it == 0 && vc[0] < -c.bounce_threshold)     // restitution: leave with e x the approach speed
+                C.vtarget = std::max(C.vtarget, -0.5f * (mat[0] + c.ground_restitution) * vc[0]);
             float ln = std::max(0.0f, old[0] - C.relax * (vc[0] - C.vtarget) * C.iW[0]);
             float dn = ln - old[0];
             vc[1] += C.W[1][0] * dn;

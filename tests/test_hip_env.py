@@ -62,15 +62,23 @@ def _seed_state(envs, rng, n, A, z0, origins=None, spread=0.02):
 
 
 @pytest.mark.parametrize("name,z0", [("anymal_c_flat", 0.50), ("anymal_c_rough", 0.55), ("cassie", 0.85),
-                                     ("anymal_c_allrewards", 0.30), ("a1", 0.28), ("anymal_b", 0.50)])
+                                     ("anymal_c_allrewards", 0.30), ("a1", 0.28), ("anymal_b", 0.50), ("anymal_c_randomised", 0.50)])
 def test_physics_substep_matches_oracle(name, z0, oracle_built):
     """One sim_dt of ABA + contact: HIP lane-parallel kernel vs the scalar oracle.
     Tolerance: 2e-4 abs/rel on state, 0.5 N + 2e-3 rel on contact forces (fp32, different
-    summation order at the base)."""
+    summation order at the base).  anymal_c_randomised: per-env restitution / compliance / thickness (lg_buffers.material) live in
+    the contact law."""
     hip, ora, z, meta = _pair(name, oracle_built, n=256)
     try:
         rng = np.random.default_rng(3)
         n, A = 256, meta["num_dofs"]
+        if name == "anymal_c_randomised":
+            assert hip.core.cfg_struct.material_rand == 1
+            mat = np.zeros((n, 4), np.float32)
+            mat[:, 0], mat[:, 1], mat[:, 2] = rng.uniform(0, 1, n), rng.uniform(0, 2e-6, n), rng.uniform(0, 0.03, n)
+            mat[::7] = 0.0
+            for e in (hip, ora):
+                e.set("material", mat)
         origins = z["const_env_origins_init"][rng.integers(0, len(z["const_env_origins_init"]), n)] if meta["custom_origins"] else None
         _seed_state([hip, ora], rng, n, A, z0, origins)
         tau = rng.uniform(-20, 20, (n, A)).astype(np.float32)

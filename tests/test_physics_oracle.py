@@ -289,3 +289,53 @@ def test_joint_limits_hold_against_torque(robot, oracle_built):
         assert np.all(np.abs(d[3, last, 0] - hi[last]) < 0.03) and np.all(np.abs(d[3, last, 1]) < 0.5)
     finally:
         env.close()
+
+
+def test_shape_material_parameters_act_on_the_contacts(oracle_built):
+    """The randomised rigid-shape properties of legged_robot.py:284-299 as the sphere-set contact model carries them (one material
+    per robot, lg_buffers.material): thickness = rest offset (the stance settles that much higher), restitution = the contact leaves
+    with e x its approach speed when that exceeds sim.physx.bounce_threshold_velocity (a dropped robot rebounds, e = 0 does not),
+    compliance = constraint-force mixing on the normal row (a softer contact sinks deeper under the same weight).  Env 0 carries
+    the asset defaults (zeros) and must behave exactly as with the randomisation switched off."""
+    cfg = _cfg("anymal_c", n=4)
+    cfg.control.control_type, cfg.control.action_scale = "P", 0.5
+    rsp = cfg.domain_rand.rigid_shape_properties
+    rsp.randomize_restitution = rsp.randomize_compliance = rsp.randomize_thickness = True
+    env, cm, cfg = _make("anymal_c", oracle_built, cfg=cfg)
+    ref, _, _ = _make("anymal_c", oracle_built, cfg=(lambda c: (setattr(c.control, "control_type", "P"), setattr(c.control, "action_scale", 0.5), c)[-1])(_cfg("anymal_c", n=4)))
+    try:
+        assert env.setup.to_structs()[0].material_rand == 1 and ref.setup.to_structs()[0].material_rand == 0
+        n, A = 4, cm["num_dofs"]
+        mat = np.zeros((n, 4), np.float32)
+        mat[1, 2] = 0.02                                   # thickness
+        mat[2, 0] = 1.6                                    # restitution (combined with the plane's 0 by averaging: e = 0.8)
+        mat[3, 1] = 2.0e-6                                 # compliance, m/N
+        env.set("material", mat)
+
+        def settle(e, z0, vz0, steps):
+            root = np.zeros((n, 13), np.float32)
+            root[:, 2], root[:, 6], root[:, 9] = z0, 1.0, vz0
+            dof = np.zeros((n, A, 2), np.float32)
+            dof[..., 0] = e.setup.default_dof_pos
+            e.set("root_states", root)
+            e.set("dof_state", dof)
+            e.set("friction", np.ones(n, np.float32))
+            e.set_actions(np.zeros((n, A), np.float32))
+            fz = []
+            for _ in range(steps):
+                e.call("compute_torques")
+                e.call("simulate")
+                fz.append(e.get("contact_forces")[:, e.setup.feet_indices, 2].sum(1))
+            return e.get("root_states").copy(), np.array(fz)
+        r_env, _ = settle(env, 0.56, 0.0, 400)
+        r_ref, _ = settle(ref, 0.56, 0.0, 400)
+        np.testing.assert_array_equal(r_env[0], r_ref[0])                     # defaults: bit-identical to the switch being off
+        assert abs((r_env[1, 2] - r_env[0, 2]) - 0.02) < 2e-3, r_env[:, 2]      # rests one thickness higher
+        assert 2e-4 < r_env[0, 2] - r_env[3, 2] < 5e-3, r_env[:, 2]             # 128 N per foot x 2e-6 m/N: sinks ~0.26 mm deeper
+        _, fz = settle(env, 0.75, -1.5, 60)                                   # dropped: the feet arrive at ~2.5 m/s
+        first = int(np.argmax(fz[:, 0] > 0))
+        airborne = (fz[first:] == 0).sum(0)             # substeps without foot contact after the first touch-down
+        assert first > 5 and airborne[0] == 0 and airborne[2] >= 5, (first, airborne)   # e = 0 sticks, e = 0.8 rebounds off the ground
+    finally:
+        env.close()
+        ref.close()
