@@ -29,7 +29,8 @@ MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_
 MFMA_BF16_PEAK_TF = 2500.0     # bf16 MFMA dense peak (MI355X_MICROARCH.md); the split-bf16 GEMM issues 6 bf16 MFMAs per
 MFMA_X6_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32 product block, so its fp32-equivalent ceiling is 2500 / 6 = 416.7 TFLOP/s
 BYTES_PER_ENV_STEP = 4200.0    # flat ANYmal, fused-step algorithmic bytes
-PMC_FILE = "r02_pmc_traffic.json" if os.path.isfile(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) else "r01_pmc_traffic.json"
+PMC_FILE = next((f"r{n:02d}_pmc_traffic.json" for n in range(9, 0, -1)        # the latest round's committed PMC digest
+                 if os.path.isfile(os.path.join(ROOT, "profiles", f"r{n:02d}_pmc_traffic.json"))), "r01_pmc_traffic.json")
 
 
 def macs_per_sample(obs, hidden, actions):
@@ -96,7 +97,7 @@ def time_iterations(runner, steps, warmup, world):
     return el, t_roll * steps
 
 
-def gemm_roofline(runner, hidden, with_largest=True):
+def gemm_roofline(runner, hidden, with_largest=True, task="anymal_c_flat"):
     """GEMM group of one minibatch (forward + head + backward of actor and critic: everything lg_ppo_minibatch_backward
     launches), timed live with HIP events on the launch stream INSIDE a real update -- begin_update, then epochs x minibatches
     of {backward, optimiser step} as HipPPO.update() runs them, the events bracketing each backward (the optimiser step, which
@@ -124,9 +125,10 @@ def gemm_roofline(runner, hidden, with_largest=True):
     ach = flops / (ms * 1e-3) / 1e12
     traffic = None                                  # HBM bytes per minibatch group from the committed PMC passes
     try:
-        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+        name = PMC_FILE if task == "anymal_c_flat" else PMC_FILE.replace("_pmc_traffic", f"_{task}_pmc_traffic")
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             pm = json.load(f)
-        if pm.get("policy_hidden") == list(hidden):
+        if pm.get("policy_hidden") == list(hidden) and pm.get("task", "anymal_c_flat") == task:
             traffic = pm["gemm_group_bytes_per_minibatch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -280,7 +282,7 @@ def other_config(task, num_envs, hidden, device, steps=6, warmup=3):
     try:
         env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
         el, t_roll = time_iterations(runner, steps, warmup, 1)
-        rf = gemm_roofline(runner, hidden, with_largest=False)
+        rf = gemm_roofline(runner, hidden, with_largest=False, task=task)
         ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
         iters = steps + warmup + 2 + 1                     # timed + warm-up + the two split iterations + the roofline's update
         out = {"task": task, "num_envs": num_envs, "num_obs": env.num_obs, "policy_hidden": list(hidden),
@@ -289,7 +291,7 @@ def other_config(task, num_envs, hidden, device, steps=6, warmup=3):
                "value": round(runner.num_steps_per_env * num_envs * steps / el, 1), "unit": "env-steps/s",
                "ms_per_step": round(1e3 * el / steps, 3), "rollout_ms": round(1e3 * t_roll / steps, 3),
                "update_ms": round(1e3 * (el - t_roll) / steps, 3),
-               "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "ms_per_minibatch", "flops_per_minibatch")},
+               "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_minibatch", "flops_per_minibatch")},
                "us_per_lg_step": round(lg_step_us(env), 2),
                "resets_per_env_step": round(ep_done / max(runner.num_steps_per_env * num_envs * (iters - 1), 1), 5),
                "physics_fault_resets": int(env.fault_total.cpu())}
@@ -370,6 +372,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num_envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--hidden", type=str, default="512,256,128")
+    ap.add_argument("--task", type=str, default="anymal_c_flat", help="registered task of the main line (profiling other configs)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt", action="store_true", help="skip the [128,64,32] pass (profiling runs)")
     ap.add_argument("--no_other", action="store_true", help="skip the anymal_c_rough / cassie passes (BASELINE configs[2], [4])")
@@ -400,7 +403,10 @@ def main():
             torch.distributed.init_process_group(backend)
     if os.environ.get("LG_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook: a rank that dies must fail the job
         raise SystemExit(3)
-    env, runner = make_runner(args.num_envs, hidden, device, rank, world)
+    env, runner = make_runner(args.num_envs, hidden, device, rank, world, task=args.task)
+    if args.task != "anymal_c_flat":
+        env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        args.no_other = args.no_alt = args.no_cpu_baseline = True
     el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world
     sustained = None
@@ -430,11 +436,13 @@ def main():
                              "hundreds of iterations PPO's entropy bonus alone inflates the policy's std and its actions (|a| up to the clip of "
                              "100): robots thrash, resets per env-step rise 3x and a few envs per million steps exceed the physics guard's "
                              "141 rad/s (tools/diag_faults.py, profiles/r03_diag_faults.txt).  Workload drift and power state both enter this figure"}
-    out = {"metric": f"env-steps/sec (whole node), ANYmal-C flat {args.num_envs} envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
+    label = "ANYmal-C flat" if args.task == "anymal_c_flat" else args.task
+    out = {"metric": f"env-steps/sec (whole node), {label} {args.num_envs} envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"anymal_c_flat, {args.num_envs} envs/GPU, 24 env steps/iter (decimation 4, actuator LSTM, "
+           "config": {"workload": f"{args.task}, {args.num_envs} envs/GPU, 24 env steps/iter (decimation 4, "
+                                  f"{'actuator LSTM' if env.setup.use_actuator_net else 'PD law'}, "
                                   f"ABA+contact), PPO 5 epochs x 4 minibatches, ActorCritic {hidden}",
                       "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden, "parallelism": f"env-shard x{world}",
                       "rollout_ms": round(1e3 * t_roll / args.steps, 3),
@@ -444,10 +452,10 @@ def main():
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
     out["config"]["physics_fault_resets"] = faults
     if rank == 0 and world == 1:
-        out["roofline"] = gemm_roofline(runner, hidden)
+        out["roofline"] = gemm_roofline(runner, hidden, task=args.task)
         out["roofline"]["traffic_source"] = ("committed PMC passes of this command (profiles/" + PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / "
                                              "WRITE_SIZE in separate runs); not collected during this run")
-        out["roofline_env_step"] = env_roofline(env)
+        out["roofline_env_step"] = env_roofline(env) if args.task == "anymal_c_flat" else {"us_per_lg_step": round(lg_step_us(env), 2)}
         env.close()
         runner.ppo.close()
         if not args.no_other:

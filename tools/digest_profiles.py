@@ -7,7 +7,8 @@ both in KiB) and rNN_pmc_traffic.json (what bench.py reports as roofline.traffic
 """
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"          # "r03" or "r03_anymal_c_rough" (rocprofv3 passes of bench.py --task ...)
+task = tag.split("_", 1)[1] if "_" in tag else "anymal_c_flat"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
@@ -64,7 +65,7 @@ st = names[si[0]:si[1]]                         # one policy step: substeps .. a
 kib = lambda n: (2.0 * sum(fetch[n]) / len(fetch[n]) if n in fetch else 0.0) + (sum(write[n]) / len(write[n]) if n in write else 0.0)
 group = [n for n in mb if "k_gemm" in n or n.startswith("k_loss") or "k_head" in n]      # what lg_ppo_minibatch_backward launches inside an update
 envk = [n for n in st if "k_substeps" in n or "k_post_step" in n or "k_finalize" in n]
-out = {"policy_hidden": [512, 256, 128],
+out = {"policy_hidden": [512, 256, 128], "task": task,
        "gemm_group_bytes_per_minibatch": round(1024.0 * sum(kib(n) for n in group)),
        "gemm_group_launches": len(group),
        "env_step_bytes_per_call": round(1024.0 * sum(kib(n) for n in envk)),
