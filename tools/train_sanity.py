@@ -42,7 +42,15 @@ if robot == "anymal_c_trajectory":
     for k, v in dict(termination=-0.5, tracking_rom=6.0, ang_vel_xy=-0.05, orientation=-1.0, torques=-1e-5, dof_acc=-2.5e-7, collision=-1.0,
                      action_rate=-0.1, feet_air_time=0.0).items():
         setattr(env_cfg.rewards.scales, k, v)
-    mode = "as launched by the authors"
+    if mode == "curriculum":
+        # the authors' staged curriculum (deep_tube_learning/configs/rl/default.yaml:77-109: three stages -- pushes 0.1 / 0.5 / 1 x,
+        # hold times 3 / 2 / 1 x, ROM speed 0.5 / 0.75 / 1 x, tracking sigma and every reward scale 1 / 0.8 / 0.6 x), with the stage
+        # changes at 60 and 120 iterations (24 policy steps each) so that a 200-iteration run shows all three
+        env_cfg.curriculum.use_curriculum = True
+        env_cfg.curriculum.curriculum_steps = [24 * 60, 24 * 120]
+        env_cfg.rewards.scales.feet_air_time = 0.0
+    else:
+        mode = "as launched by the authors"
 if robot == "a1":
     from legged_gym_dev_amd.envs.a1.a1_config import A1RoughCfg, A1RoughCfgPPO
     from legged_gym_dev_amd.envs.base.legged_robot import LeggedRobot as EnvCls
@@ -84,7 +92,8 @@ for it in range(iters):
         trk = float(env.extras["episode"].get(trk_key, torch.zeros(()))) if "episode" in env.extras else 0.0
         if robot == "anymal_c_trajectory":
             terr = float((env.trajectory[:, 0] - env.root_states[:, :2]).norm(dim=1).mean())
-            print(f"        mean distance to the reference trajectory {terr:.3f} m, physics faults {int(env.fault_total[0])}", flush=True)
+            print(f"        mean distance to the reference trajectory {terr:.3f} m, physics faults {int(env.fault_total[0])}, "
+                  f"curriculum stage {env.curriculum_state} (sigma {env.tracking_sigma:.3f}, v_max {float(env.rom.v_max[0]):.3f})", flush=True)
         print(f"it {it + 1:4d}  mean_return {es[0] / n:8.3f}  mean_ep_len {es[1] / n:7.1f}  episodes {int(es[2]):6d}  "
               f"std {float(ppo.param_views['std'].mean()):.3f} lr {ppo.learning_rate:.2e} vloss {float(vl):.4f}  "
               f"base_z {float(env.root_states[:, 2].mean()):.3f} rew_tracking {trk:.4f} terrain_level {lvl:.2f} nonfinite_envs {bad}", flush=True)
