@@ -415,27 +415,6 @@ def main():
     ep_done = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
     steps_done = runner.num_steps_per_env * args.num_envs * (args.steps + args.warmup + 2)
     faults = int(env.fault_total.cpu())
-    if args.sustained > 0 and world == 1:
-        # the timed K steps are a burst of a few hundred ms; a training run settles at the power / thermal state of minutes
-        # of load.  Same loop, `sustained` iterations, no host synchronisation inside.
-        ar = runner._grad_reduce
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.sustained):
-            runner.rollout()
-            runner.ppo.update(ar)
-        torch.cuda.synchronize()
-        s_el = time.perf_counter() - t0
-        ep2 = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
-        sustained = {"iterations": args.sustained, "value": round(steps_per_iter * args.sustained / s_el, 1), "unit": "env-steps/s",
-                     "ms_per_step": round(1e3 * s_el / args.sustained, 3), "seconds": round(s_el, 2),
-                     "resets_per_env_step": round((ep2 - ep_done) / (steps_per_iter * args.sustained), 5),
-                     "physics_fault_resets": int(env.fault_total.cpu()) - faults,
-                     "policy_std_at_end": round(float(runner.ppo.param_views["std"].mean()), 3),
-                     "note": "the fork's anymal_c_flat reward is identically 0 after its positive clip (commands x, y = 0: SURVEY.md 0.8), so over "
-                             "hundreds of iterations PPO's entropy bonus alone inflates the policy's std and its actions (|a| up to the clip of "
-                             "100): robots thrash, resets per env-step rise 3x and a few envs per million steps exceed the physics guard's "
-                             "141 rad/s (tools/diag_faults.py, profiles/r03_diag_faults.txt).  Workload drift and power state both enter this figure"}
     label = "ANYmal-C flat" if args.task == "anymal_c_flat" else args.task
     out = {"metric": f"env-steps/sec (whole node), {label} {args.num_envs} envs per GPU", "value": round(steps_per_iter * args.steps / el, 1),
            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -447,8 +426,6 @@ def main():
                       "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden, "parallelism": f"env-shard x{world}",
                       "rollout_ms": round(1e3 * t_roll / args.steps, 3),
                       "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
-    if sustained:
-        out["sustained"] = sustained
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
     out["config"]["physics_fault_resets"] = faults
     if rank == 0 and world == 1:
@@ -456,6 +433,31 @@ def main():
         out["roofline"]["traffic_source"] = ("committed PMC passes of this command (profiles/" + PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / "
                                              "WRITE_SIZE in separate runs); not collected during this run")
         out["roofline_env_step"] = env_roofline(env) if args.task == "anymal_c_flat" else {"us_per_lg_step": round(lg_step_us(env), 2)}
+        if args.sustained > 0:   # after the probes above: they are taken in the state the timed steps ran in
+            # the timed K steps are a burst of a few hundred ms; a training run settles at the power / thermal state of minutes
+            # of load.  Same loop, `sustained` iterations, no host synchronisation inside.
+            ar = runner._grad_reduce
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.sustained):
+                runner.rollout()
+                runner.ppo.update(ar)
+            torch.cuda.synchronize()
+            s_el = time.perf_counter() - t0
+            ep2 = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
+            sustained = {"iterations": args.sustained, "value": round(steps_per_iter * args.sustained / s_el, 1), "unit": "env-steps/s",
+                         "ms_per_step": round(1e3 * s_el / args.sustained, 3), "seconds": round(s_el, 2),
+                         "resets_per_env_step": round((ep2 - ep_done) / (steps_per_iter * args.sustained), 5),
+                         "physics_fault_resets": int(env.fault_total.cpu()) - faults,
+                         "policy_std_at_end": round(float(runner.ppo.param_views["std"].mean()), 3),
+                         "note": "the fork's anymal_c_flat reward is identically 0 after its positive clip (commands x, y = 0: SURVEY.md 0.8), so over "
+                                 "hundreds of iterations PPO's entropy bonus alone inflates the policy's std and its actions (|a| up to the clip of "
+                                 "100): robots thrash, resets per env-step rise 3x and a few envs per million steps exceed the physics guard's "
+                                 "141 rad/s (tools/diag_faults.py, profiles/r03_diag_faults.txt).  Workload drift and power state both enter this figure"}
+        if sustained:
+            # the same GEMM-group probe in the state the sustained pass leaves the chip in (power / clocks), beside the burst-state one
+            sustained["gemm_ms_per_minibatch_at_end"] = gemm_roofline(runner, hidden, with_largest=False, task=args.task)["ms_per_minibatch"]
+            out["sustained"] = sustained
         env.close()
         runner.ppo.close()
         if not args.no_other:
