@@ -70,8 +70,10 @@ struct lg_ppo {
     Net net[2];                              // 0 actor, 1 critic
     hipStream_t stream;
     hipStream_t side;                        // weight-gradient GEMMs run here, overlapping the input-gradient chain
-    hipEvent_t ev_dz, ev_side;
+    hipStream_t side2;                       // the first layer's weight gradient over the rows the layer-2 input gradient has produced already
+    hipEvent_t ev_dz, ev_side, ev_half, ev_side2;
     int overlap;
+    int dw0_early;                           // LG_DW0_EARLY (backward())
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;
     // fused rollout epilogue (lg_ppo_attach_env): a process_env_step recorded for the next act launch
@@ -175,6 +177,12 @@ static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
 static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int skip_head = 0) {
     const float *in[2] = {in0, in1};
     const int nl = p->net[0].nl;
+    // LG_DW0_EARLY: the last weight gradient (layer 0) has nothing to overlap with once the input-gradient chain is done -- it used to
+    // run alone at the tail re-reading dz_1.  The layer-1 input gradient is launched as two row halves instead; the layer-0 weight
+    // gradient of the first half (its reduction runs over rows) starts on a third stream as soon as that half exists, beside the
+    // second half and the layer-1 weight gradient; only the second half's is left for the tail.
+    const int half = (M / 2) & ~255;
+    const bool early = p->dw0_early && p->overlap && !p->comm && nl >= 2 && half >= 2048;
     for (int l = nl - 1 - skip_head; l >= 0; --l) {
         GemmArgs g;
         memset(&g, 0, sizeof(g));
@@ -213,6 +221,13 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
             (void)hipEventRecord(p->ev_dz, p->stream);
             (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
         }
+        if (l == 0 && early) {                       // rows [half, M): the first half went out beside the layer-1 input gradient
+            for (int z = 0; z < 2; ++z) {
+                g.A[z] += (size_t)half * g.lda[z]; g.B[z] += (size_t)half * g.ldb[z]; g.K[z] = M - half;
+            }
+            int s2 = splits / 2 >= 8 ? (splits / 2) & ~7 : (splits / 2 > 0 ? splits / 2 : 1);
+            ppok_gemm_dw(&g, 2, s2, dw_stream);
+        } else
         ppok_gemm_dw(&g, 2, splits, dw_stream);
         if (p->comm) reduce_layer_bucket(p, l, dw_stream);
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * act'(act[l]); db_{l-1} = colsum(dz[l])
@@ -229,12 +244,46 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
             }
             g.elu = p->act_code;                         // derivative of the hidden activation, through its output act[l]
             g.pl_stride = p->dev.pl_stride;
+            if (l == 1 && early) {
+                GemmArgs h0 = g, h1 = g;
+                for (int z = 0; z < 2; ++z) {
+                    h0.M[z] = half;
+                    h1.M[z] = M - half;
+                    h1.A[z] += (size_t)half * g.lda[z]; h1.C[z] += (size_t)half * g.ldc[z]; h1.aux[z] += (size_t)half * g.ldaux[z];
+                }
+                ppok_gemm_dx(&h0, 2, p->stream);
+                (void)hipEventRecord(p->ev_half, p->stream);
+                (void)hipStreamWaitEvent(p->side2, p->ev_half, 0);
+                GemmArgs w;                              // dW_0 over rows [0, half)
+                memset(&w, 0, sizeof(w));
+                long tiles = 0;
+                for (int z = 0; z < 2; ++z) {
+                    Net &n = p->net[z];
+                    w.A[z] = n.dz[1]; w.lda[z] = n.dims[1];
+                    w.B[z] = in[z]; w.ldb[z] = z == 0 ? p->dev.Op : p->dev.OCp;
+                    w.C[z] = p->dev.grads + n.w_off[0]; w.ldc[z] = n.dims[0];
+                    w.M[z] = n.dims[1]; w.N[z] = n.dims[0]; w.K[z] = half;
+                    if (w.ldb[z] != n.dims[0]) { w.N[z] = w.ldb[z]; w.nstore[z] = n.dims[0]; }
+                    const int tile = (w.M[z] > 64 && w.N[z] > 64) ? 128 : 64;
+                    long t = (long)((w.M[z] + tile - 1) / tile) * ((w.N[z] + tile - 1) / tile);
+                    tiles = t > tiles ? t : tiles;
+                }
+                static const int dw_target = getenv("LG_DW_WGS") ? atoi(getenv("LG_DW_WGS")) : 384;
+                int s0 = (int)((dw_target / 2 + tiles - 1) / tiles);
+                if (s0 > half / 256) s0 = half / 256;
+                if (s0 >= 8) s0 &= ~7;
+                if (s0 < 1) s0 = 1;
+                ppok_gemm_dw(&w, 2, s0, p->side2);
+                (void)hipEventRecord(p->ev_side2, p->side2);
+                ppok_gemm_dx(&h1, 2, p->stream);
+            } else
             ppok_gemm_dx(&g, 2, p->stream);
         }
     }
     if (p->overlap) {                                // join: the optimiser step (main stream) needs every dW
         (void)hipEventRecord(p->ev_side, p->side);
         (void)hipStreamWaitEvent(p->stream, p->ev_side, 0);
+        if (early) (void)hipStreamWaitEvent(p->stream, p->ev_side2, 0);
     }
     if (p->comm) {                                   // ... and every reduced bucket
         (void)hipEventRecord(lg_comm_event_(p->comm), lg_comm_stream_(p->comm));
@@ -260,6 +309,9 @@ int lg_ppo_destroy(lg_ppo *p) {
     if (!p) return 0;
     if (p->env) { flush_rollout_epilogue(p); lg_internal_defer_finalize(p->env, 0); p->env = nullptr; }
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
+    if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
+    if (p->ev_half) (void)hipEventDestroy(p->ev_half);
+    if (p->ev_side2) (void)hipEventDestroy(p->ev_side2);
     if (p->ev_dz) (void)hipEventDestroy(p->ev_dz);
     if (p->ev_side) (void)hipEventDestroy(p->ev_side);
     if (p->ev_bucket) (void)hipEventDestroy(p->ev_bucket);
@@ -285,7 +337,11 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->act_code = cfg->activation + 1;
     p->fused_act = getenv("LG_FUSED_ACT") ? atoi(getenv("LG_FUSED_ACT")) : 1;   // one-launch rollout forward (ppo_mlp_fused.hip) when the shape allows
     p->overlap = getenv("LG_PPO_OVERLAP") ? atoi(getenv("LG_PPO_OVERLAP")) : 1;
+    p->dw0_early = getenv("LG_DW0_EARLY") ? atoi(getenv("LG_DW0_EARLY")) : 1;
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_half, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_side2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_bucket, hipEventDisableTiming) != hipSuccess) {
@@ -425,6 +481,7 @@ int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out) { *out = p->pub; return 0
 int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0; }
 int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
 int lg_ppo_debug_set_overlap(lg_ppo *p, int v) { p->overlap = v; return 0; }
+int lg_ppo_debug_set_dw0_early(lg_ppo *p, int v) { p->dw0_early = v; return 0; }
 int lg_ppo_debug_set_fused_act(lg_ppo *p, int v) { p->fused_act = v && p->mlp.wfrag; return 0; }
 int lg_ppo_debug_get_fused_act(lg_ppo *p) { return p->fused_act; }          // 1: lg_ppo_act runs the one-launch forward for this shape
 int lg_ppo_debug_set_act_count(lg_ppo *p, long long v) { p->act_count = v; return 0; }   // replay the same Philox draws (tests)
