@@ -722,14 +722,14 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     //       loads first, term values into LDS, stores last -- a store to a state buffer in the middle makes every later
     //       load wait for it (the buffers may alias as far as the compiler knows);
     //   A3  all lanes: episode sums (+ the logging sums of the envs that reset).
-    static_assert(TILE * 16 == LG_TILE_THREADS, "phase A: 16 lanes per environment");
+    static_assert(TILE * 16 <= LG_TILE_THREADS && LG_TILE_THREADS % 64 == 0, "phase A: 16 lanes per environment on the first TILE rows of lanes");
     __shared__ float s_tv[TILE][LG_NUM_TERMS];
     __shared__ float s_fr[TILE][9];
     __shared__ float s_win[TILE][LG_TG_WIN];                          // trajectory env: the generator window of each env's phase-A lane
     __shared__ float s_js[TILE][JS_N];
     __shared__ uint8_t s_rst[TILE];
     const int e16 = tid >> 4, l16 = tid & 15;
-    {
+    if (e16 < TILE) {                                                 // (wave-uniform: TILE rows of 16 lanes are whole waves)
         const int i = env0 + min(e16, nE - 1);
         float pj[JS_N];
 #pragma unroll

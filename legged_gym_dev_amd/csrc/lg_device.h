@@ -6,7 +6,11 @@
 #include "../../include/legged_hip.h"
 
 #define LG_WAVE 64
-#define LG_TILE_THREADS 256
+#ifndef LG_TILE_THREADS
+#define LG_TILE_THREADS 512         // threads of a post-step workgroup (16 envs): the height scan, the observation segments and the noise
+                                    // pass are lane-parallel over (env, entry), so 32 lanes per env halve their trips -- 23.9 -> 18.8 us
+                                    // rough terrain, 49.8 -> 46.7 Cassie, flat unchanged (256: phase A's 16 lanes per env only)
+#endif
 #define LG_MAX_LEG_SLOTS 6
 #define LG_MAX_BASE_PER_LANE 2      // base collision spheres are dealt to the lanes of an env: sphere b -> lane b % L, slot b / L
 #define LG_NUM_SLOTS (LG_MAX_LEG_SLOTS + LG_MAX_BASE_PER_LANE)

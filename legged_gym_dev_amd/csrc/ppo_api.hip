@@ -177,8 +177,8 @@ static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
 static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int skip_head = 0) {
     const float *in[2] = {in0, in1};
     const int nl = p->net[0].nl;
-    // LG_DW0_EARLY: the last weight gradient (layer 0) has nothing to overlap with once the input-gradient chain is done -- it used to
-    // run alone at the tail re-reading dz_1.  The layer-1 input gradient is launched as two row halves instead; the layer-0 weight
+    // LG_DW0_EARLY (A/B, off: the backward phase is bound by total machine work, co-running a third kernel only redistributes it --
+    // 0.486 vs 0.475 ms per minibatch, profiles/r03_ab.txt): the last weight gradient (layer 0) runs alone at the tail re-reading dz_1.  The layer-1 input gradient is launched as two row halves instead; the layer-0 weight
     // gradient of the first half (its reduction runs over rows) starts on a third stream as soon as that half exists, beside the
     // second half and the layer-1 weight gradient; only the second half's is left for the tail.
     const int half = (M / 2) & ~255;
@@ -337,7 +337,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->act_code = cfg->activation + 1;
     p->fused_act = getenv("LG_FUSED_ACT") ? atoi(getenv("LG_FUSED_ACT")) : 1;   // one-launch rollout forward (ppo_mlp_fused.hip) when the shape allows
     p->overlap = getenv("LG_PPO_OVERLAP") ? atoi(getenv("LG_PPO_OVERLAP")) : 1;
-    p->dw0_early = getenv("LG_DW0_EARLY") ? atoi(getenv("LG_DW0_EARLY")) : 1;
+    p->dw0_early = getenv("LG_DW0_EARLY") ? atoi(getenv("LG_DW0_EARLY")) : 0;   // measured slower: 0.486 vs 0.475 ms per minibatch
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_half, hipEventDisableTiming) != hipSuccess ||

@@ -218,6 +218,18 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const
 // four different bank phases while fragment reads (32 consecutive rows) stay conflict-free.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define X6_ROWB 80
+// Workgroup barrier of the GEMM mainloops: LDS traffic only.  __syncthreads() carries workgroup-scope fences, for which hipcc drains
+// EVERY outstanding memory operation (s_waitcnt vmcnt(0)) -- including the global loads issued two k-tiles ahead, whose latency
+// the prefetch distance exists to hide.  The mainloops exchange data through LDS alone: waiting for this wave's LDS operations
+// and the barrier is all the ordering they need; the loaded registers are waited for where they are used (counted vmcnt).
+// LG_GEMM_FULL_BARRIER (compile-time, A/B) restores __syncthreads().
+__device__ __forceinline__ void lds_barrier() {
+#ifdef LG_GEMM_FULL_BARRIER
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     uint32_t r;
@@ -410,7 +422,7 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     for (int d = 1; d < PD; ++d)
         if (k_begin + d * BK < k_end) load_tile(R[d], k_begin + d * BK);
     store_tile(R[0], 0);
-    __syncthreads();
+    lds_barrier();
     // fragment of tile a, plane p, k-step s: base + a*8*X6_ROWB (32 logical rows = 8 physical) + p*PL + s*32
     const unsigned char *fa = lds + x6_prow<BM>(wm + li) * X6_ROWB + 16 * lk;
     const unsigned char *fb = lds_b + x6_prow<BN>(wn + li) * X6_ROWB + 16 * lk;
@@ -480,10 +492,10 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
                 }
         }
         if constexpr (!LDB) {
-            __syncthreads();                     // every wave is done reading before the tile is refilled
+            lds_barrier();                     // every wave is done reading before the tile is refilled
             if (k0 + BK < k_end) store_tile(x, 0);
         }
-        __syncthreads();
+        lds_barrier();
     };
     for (int k0 = k_begin; k0 < k_end; k0 += PD * BK) {
 #pragma unroll
@@ -730,7 +742,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm
     if (k_begin + BK < k_end) load(k_begin + BK, ra1, rb1, ma1, mb1);
     stage_store_x6t<BM, NT>(lds, ra0, ma0);
     stage_store_x6t<BN, NT>(lds_b, rb0, mb0);
-    __syncthreads();
+    lds_barrier();
     auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA], float4 (&yb)[NVB],
                     unsigned &yma, unsigned &ymb) {
         if (k0 + 2 * BK < k_end) load(k0 + 2 * BK, ya, yb, yma, ymb);     // two k-tiles ahead, into the set just consumed
@@ -760,12 +772,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm
                     acc[a][b] = c;
                 }
         }
-        __syncthreads();
+        lds_barrier();
         if (k0 + BK < k_end) {
             stage_store_x6t<BM, NT>(lds, xa, xma);
             stage_store_x6t<BN, NT>(lds_b, xb, xmb);
         }
-        __syncthreads();
+        lds_barrier();
     };
     for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
         body(k0, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
