@@ -542,9 +542,19 @@ __device__ void reset_env(const DevParams *P, int i, int64_t counter, int inject
 // that resets would otherwise keep one lane busy for ~2.5 k instructions -- 20+ Philox draws, ~150 stores -- while the
 // block's other lanes wait, and the kernel lasts as long as its slowest block).  Same arithmetic, same Philox slots, so
 // the result is bit-identical to reset_env; only who computes what changes.  Call from all threads (contains barriers).
+// WAVE = true: the same by ONE wave, no barriers (its lanes run in step; a workgroup-scope fence orders the global stores of one
+// lane before the loads of another) -- the waves of k_post_step each take one of the tile's resetting envs, so a workgroup with
+// two or three resets (Cassie under a random policy: 55 resets per step) lasts as long as one with a single reset.  The caller
+// places a barrier after its last reset.
+template <bool WAVE = false>
 __device__ __forceinline__ void reset_env_coop(const DevParams *P, int i, int64_t counter, int inject, int init_done, float *__restrict__ win) {
     const lg_cfg &c = P->cfg;
-    const int A = c.num_actions, N = c.num_envs, F = c.num_feet, tid = threadIdx.x;
+    const int A = c.num_actions, N = c.num_envs, F = c.num_feet;
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nthr = WAVE ? 64 : (int)blockDim.x;
+    auto sync = [&]() __attribute__((always_inline)) {
+        if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        else __syncthreads();
+    };
     float *r = P->buf.root_states + (size_t)i * 13;
     float *org = P->buf.env_origins + (size_t)i * 3;
     if (tid == 0 && c.curriculum && init_done) {                  // needs the pre-reset pose and commands
@@ -566,42 +576,44 @@ __device__ __forceinline__ void reset_env_coop(const DevParams *P, int i, int64_
         const float *to = P->terrain_origins + ((size_t)lvl * c.terrain_num_cols + P->buf.terrain_types[i]) * 3;
         org[0] = to[0]; org[1] = to[1]; org[2] = to[2];
     }
-    __syncthreads();
+    sync();
     const bool tj = c.traj.enabled;
     const int s_dof = tj ? LG_TSLOT_DOF : LG_SLOT_DOF, s_xy = tj ? LG_TSLOT_XY(A) : LG_SLOT_XY(A), s_vel = tj ? LG_TSLOT_VEL(A) : LG_SLOT_VEL(A);
-    if (tid < A) {                                                 // joint j = tid
-        const float u = uni(P, i, s_dof + tid, counter, inject);
-        reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)i * A + tid] = make_float2(c.default_dof_pos[tid] * ((1.5f - 0.5f) * u + 0.5f), 0.0f);
-        P->buf.last_actions[(size_t)i * A + tid] = 0.0f;
-        P->buf.last_dof_vel[(size_t)i * A + tid] = 0.0f;
-    } else if (tid < A + 13) {                                     // root component k
-        const int k = tid - A;
-        float v = c.base_init_state[k];
-        if (k < 3) v += org[k];
-        if (k < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * uni(P, i, s_xy + k, counter, inject) + (-1.0f);
-        if (k >= 7) v = (0.5f - (-0.5f)) * uni(P, i, s_vel + (k - 7), counter, inject) + (-0.5f);
-        r[k] = v;
-    } else if (tid == A + 13) {
-        if (!tj) resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject, c.cmd_lo, c.cmd_hi);
-        P->buf.episode_length[i] = 0;
-        P->buf.reset[i] = 1;
-        P->reset_mark[i] = 1;
-    } else if (tid < A + 14 + F) {
-        P->buf.feet_air_time[(size_t)i * F + (tid - A - 14)] = 0.0f;
+    for (int t = tid; t < A + 14 + F; t += nthr) {                 // one role per lane
+        if (t < A) {                                               // joint j = t
+            const float u = uni(P, i, s_dof + t, counter, inject);
+            reinterpret_cast<float2 *>(P->buf.dof_state)[(size_t)i * A + t] = make_float2(c.default_dof_pos[t] * ((1.5f - 0.5f) * u + 0.5f), 0.0f);
+            P->buf.last_actions[(size_t)i * A + t] = 0.0f;
+            P->buf.last_dof_vel[(size_t)i * A + t] = 0.0f;
+        } else if (t < A + 13) {                                   // root component k
+            const int k = t - A;
+            float v = c.base_init_state[k];
+            if (k < 3) v += org[k];
+            if (k < 2 && c.custom_origins) v += (1.0f - (-1.0f)) * uni(P, i, s_xy + k, counter, inject) + (-1.0f);
+            if (k >= 7) v = (0.5f - (-0.5f)) * uni(P, i, s_vel + (k - 7), counter, inject) + (-0.5f);
+            r[k] = v;
+        } else if (t == A + 13) {
+            if (!tj) resample_commands(P, i, LG_SLOT_RCMD(A), counter, inject, c.cmd_lo, c.cmd_hi);
+            P->buf.episode_length[i] = 0;
+            P->buf.reset[i] = 1;
+            P->reset_mark[i] = 1;
+        } else {
+            P->buf.feet_air_time[(size_t)i * F + (t - A - 14)] = 0.0f;
+        }
     }
     if (c.use_actuator_net) {                                      // h, c of both layers: 2 x A rows of 8 floats each
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = tid; q < 2 * A * 2; q += blockDim.x) {        // q = (layer, joint, half)
+        for (int q = tid; q < 2 * A * 2; q += nthr) {        // q = (layer, joint, half)
             const int l = q / (2 * A), j = (q / 2) % A, hf = q & 1;
             const size_t idx = ((size_t)l * N * A + (size_t)i * A + j) * 8 + 4 * hf;
             *reinterpret_cast<float4 *>(P->buf.lstm_h + idx) = z;
             *reinterpret_cast<float4 *>(P->buf.lstm_c + idx) = z;
         }
     }
-    __syncthreads();
+    sync();
     if (tj) {                                                      // needs the new root pose: after the barrier, one lane (a serial 10-step
         if (tid == 0) reset_trajectory(P, i, counter, inject, win);   // ROM integration; resets are rare)
-        __syncthreads();
+        sync();
     }
 }
 
@@ -723,6 +735,7 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     //       load wait for it (the buffers may alias as far as the compiler knows);
     //   A3  all lanes: episode sums (+ the logging sums of the envs that reset).
     static_assert(TILE * 16 <= LG_TILE_THREADS && LG_TILE_THREADS % 64 == 0, "phase A: 16 lanes per environment on the first TILE rows of lanes");
+    static_assert(LG_TILE_THREADS / 64 <= TILE, "phase R: one generator window (s_win row) per wave");
     __shared__ float s_tv[TILE][LG_NUM_TERMS];
     __shared__ float s_fr[TILE][9];
     __shared__ float s_win[TILE][LG_TG_WIN];                          // trajectory env: the generator window of each env's phase-A lane
@@ -856,7 +869,9 @@ __device__ __forceinline__ void post_step_tile(const DevParams *__restrict__ P, 
     }
     __syncthreads();
     STAMP(2);
-    for (int q = 0; q < s_cnt; ++q) reset_env_coop(P, s_list[q], counter, inject, init_done, s_win[0]);   // workgroup-uniform trip count
+    for (int q = tid >> 6; q < s_cnt; q += LG_TILE_THREADS / 64)      // one wave per resetting env (wave-uniform trip count)
+        reset_env_coop<true>(P, s_list[q], counter, inject, init_done, s_win[tid >> 6]);
+    if (s_cnt > 0) __syncthreads();                                   // workgroup-uniform: phase O reads what the resets wrote
     STAMP(3);
     if (s_cnt > 0) {
         if (tid < LG_NUM_TERMS && term_scale(c, tid) != 0.0f) atomicAdd(P->ep_accum + tid, s_acc[tid]);
