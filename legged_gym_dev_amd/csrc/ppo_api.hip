@@ -117,13 +117,14 @@ static int launch_ok() {
 // forward of the selected nets on M rows.  in[z] = input of net z.  mask bit z selects the net.
 // in_pad: the inputs are the minibatch gathers, rows padded to a multiple of 8 floats (PpoDev::Op / OCp); otherwise rows of dims[0]
 static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask, int skip_head = 0, bool planes = false,
-                    bool in_pad = false) {
+                    bool in_pad = false, hipStream_t on = nullptr, int l_begin = 0, int l_end = 1 << 30) {
+    const hipStream_t fs = on ? on : p->stream;
     const float *in[2] = {in0, in1};
     const int in_ld[2] = {in_pad ? p->dev.Op : p->net[0].dims[0], in_pad ? p->dev.OCp : p->net[1].dims[0]};
     int sel[2], nz = 0;
     for (int z = 0; z < 2; ++z) if (mask & (1 << z)) sel[nz++] = z;
     const int nl = p->net[sel[0]].nl;
-    for (int l = 0; l < nl - skip_head; ++l) {
+    for (int l = l_begin; l < nl - skip_head && l < l_end; ++l) {
         GemmArgs g;
         memset(&g, 0, sizeof(g));
         for (int k = 0; k < nz; ++k) {
@@ -141,7 +142,7 @@ static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int ma
         }
         g.elu = l < nl - 1 ? p->act_code : 0;
         g.pl_stride = p->dev.pl_stride;
-        ppok_gemm_fwd(&g, nz, p->stream);
+        ppok_gemm_fwd(&g, nz, fs);
     }
 }
 
@@ -625,6 +626,19 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     // long pole (profiles/r02_timelines.txt) it is 9 us faster than head GEMM + k_loss + two head-gradient GEMMs (A/B on one box)
     static const int fuse128 = getenv("LG_HEAD_FUSE128") ? atoi(getenv("LG_HEAD_FUSE128")) : 1;
     const bool fuse = p->act_code == 1 && nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32 || (H3 == 128 && fuse128));
+    // LG_FWD_SPLIT (A/B): the critic's forward chain on the side stream, one layer behind the actor's, so that the HBM-bound first
+    // layer of one net runs beside the MFMA-bound second layer of the other
+    static const int fwd_split = getenv("LG_FWD_SPLIT") ? atoi(getenv("LG_FWD_SPLIT")) : 0;
+    if (fwd_split && p->overlap && nc.nl == nl) {
+        const int sk = fuse ? 1 : 0;
+        forward(p, R, d.mb_obs, d.mb_critic_obs, 1, sk, true, true, p->stream, 0, fwd_split);
+        (void)hipEventRecord(p->ev_dz, p->stream);
+        (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
+        forward(p, R, d.mb_obs, d.mb_critic_obs, 2, sk, true, true, p->side);
+        forward(p, R, d.mb_obs, d.mb_critic_obs, 1, sk, true, true, p->stream, fwd_split);
+        (void)hipEventRecord(p->ev_side, p->side);
+        (void)hipStreamWaitEvent(p->stream, p->ev_side, 0);
+    } else
     forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true, true);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],
