@@ -357,6 +357,13 @@ int lg_ppo_attach_env(lg_ppo *p, lg_ctx *env);
 /* The caller wrote lg_ppo_buffers.params itself (checkpoint load, a broadcast of its own): the weight images the rollout forward
  * reads are re-derived by the next lg_ppo_act.  (lg_ppo_minibatch_step and lg_ppo_broadcast_params mark them stale themselves.) */
 int lg_ppo_params_changed(lg_ppo *p);
+/* Reproducible runs (debugging aid; off by default).  The learner's sums over the minibatch rows -- weight-gradient slices, bias
+ * column sums, the head's row sums, loss statistics, the gradient norm, the advantage moments -- are float atomics, whose order
+ * differs from run to run (last-bit differences in every gradient).  on != 0: the same contributions are accumulated as 2^-40
+ * fixed-point 64-bit integers (order-independent) and folded into the float buffers before they are read: two runs from the
+ * same seed then agree bit for bit, on one rank and across a fixed set of ranks.  Costs three small launches per optimiser step.
+ * Not combinable with gradient buckets reduced inside the backward pass (lg_ppo_set_comm): returns an error then. */
+int lg_ppo_set_deterministic(lg_ppo *p, int on);
 /* actor mean only (act_inference) for play/eval */
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows);
 

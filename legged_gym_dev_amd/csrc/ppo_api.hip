@@ -25,6 +25,7 @@ void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const
                      int64_t cnt, int inject, hipStream_t s);
 void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, const uint8_t *tos, int t, hipStream_t s);
 void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s);
+void ppok_det_fold(const PpoDev *P, hipStream_t s);
 void ppok_adv_normalize(const PpoDev *P, hipStream_t s);
 void ppok_gather(const PpoDev *P, int mb, hipStream_t s);
 void ppok_randperm(const PpoDev *P, int n, uint64_t update_idx, hipStream_t s);
@@ -73,6 +74,7 @@ struct lg_ppo {
     hipStream_t side2;                       // the first layer's weight gradient over the rows the layer-2 input gradient has produced already
     hipEvent_t ev_dz, ev_side, ev_half, ev_side2;
     int overlap;
+    long long *det_buf;                      // fixed-point shadow of the accumulators (lg_ppo_set_deterministic); dev.det64 = it when on
     int dw0_early;                           // LG_DW0_EARLY (backward())
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;
@@ -177,6 +179,9 @@ static void reduce_layer_bucket(lg_ppo *p, int l, hipStream_t ready_on) {
 // backward of both nets on M rows given dz[nl] (head output gradients) already filled
 static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int skip_head = 0) {
     const float *in[2] = {in0, in1};
+    auto det_args = [&](GemmArgs &g) {                // deterministic mode: gradient atomics go to the fixed-point shadow
+        g.det_base = p->dev.grads; g.det64 = p->dev.det64; g.det_n = p->dev.num_params + 2;
+    };
     const int nl = p->net[0].nl;
     // LG_DW0_EARLY (A/B, off: the backward phase is bound by total machine work, co-running a third kernel only redistributes it --
     // 0.486 vs 0.475 ms per minibatch, profiles/r03_ab.txt): the last weight gradient (layer 0) runs alone at the tail re-reading dz_1.  The layer-1 input gradient is launched as two row halves instead; the layer-0 weight
@@ -187,6 +192,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
     for (int l = nl - 1 - skip_head; l >= 0; --l) {
         GemmArgs g;
         memset(&g, 0, sizeof(g));
+        det_args(g);
         long tiles = 0;
         for (int z = 0; z < 2; ++z) {                // dW_l += dz[l+1]^T . act[l]
             Net &n = p->net[z];
@@ -233,6 +239,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         if (p->comm) reduce_layer_bucket(p, l, dw_stream);
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * act'(act[l]); db_{l-1} = colsum(dz[l])
             memset(&g, 0, sizeof(g));
+            det_args(g);
             for (int z = 0; z < 2; ++z) {
                 Net &n = p->net[z];
                 g.A[z] = n.dz[l + 1]; g.lda[z] = n.dims[l + 1];
@@ -257,6 +264,7 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
                 (void)hipStreamWaitEvent(p->side2, p->ev_half, 0);
                 GemmArgs w;                              // dW_0 over rows [0, half)
                 memset(&w, 0, sizeof(w));
+                det_args(w);
                 long tiles = 0;
                 for (int z = 0; z < 2; ++z) {
                     Net &n = p->net[z];
@@ -648,6 +656,7 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     }
     if (fuse && p->comm) reduce_layer_bucket(p, nl - 1, p->stream);   // the fused head produced the head layer's gradients itself
     backward(p, R, d.mb_obs, d.mb_critic_obs, fuse ? 1 : 0);
+    if (d.det64) ppok_det_fold(&d, p->stream);       // gradients, KL sum and loss sums of this minibatch, order-independent
     if (p->comm_rc) { const int rc = p->comm_rc; p->comm_rc = 0; return rc; }
     return launch_ok();
 }
@@ -671,13 +680,33 @@ int lg_ppo_minibatch_step(lg_ppo *p) {
 
 int lg_ppo_end_update(lg_ppo *p) { p->step = 0; return 0; }
 
-int lg_ppo_set_comm(lg_ppo *p, lg_comm *c) { p->comm = c; return 0; }
+int lg_ppo_set_comm(lg_ppo *p, lg_comm *c) {
+    if (c && p->dev.det64) { lg_set_error("gradient buckets inside the backward pass cannot be combined with deterministic mode"); return -14; }
+    p->comm = c;
+    return 0;
+}
 int lg_ppo_allreduce_adv_moments(lg_ppo *p, lg_comm *c) { return lg_comm_allreduce_sum(c, p->dev.adv_partial, 4, p->stream); }
 int lg_ppo_broadcast_params(lg_ppo *p, lg_comm *c, int root) {
     p->params_dirty = 1;
     return lg_comm_broadcast(c, p->dev.params, p->dev.num_params + 2, root, p->stream);
 }
 int lg_ppo_params_changed(lg_ppo *p) { p->params_dirty = 1; return 0; }
+
+int lg_ppo_set_deterministic(lg_ppo *p, int on) {
+    if (on && p->comm) { lg_set_error("deterministic mode cannot be combined with gradient buckets reduced inside the backward pass (lg_ppo_set_comm)"); return -14; }
+    if (on && !p->det_buf) {
+        const size_t n = (size_t)p->dev.num_params + 10;
+        void *q = nullptr;
+        if (hipMalloc(&q, n * sizeof(long long)) != hipSuccess || hipMemset(q, 0, n * sizeof(long long)) != hipSuccess) {
+            lg_set_error("hipMalloc failed in lg_ppo_set_deterministic"); return -100;
+        }
+        p->allocs.push_back(q);
+        p->det_buf = (long long *)q;
+    }
+    if (!on && p->dev.det64) ppok_det_fold(&p->dev, p->stream);    // nothing stays behind in the shadow
+    p->dev.det64 = on ? p->det_buf : nullptr;
+    return launch_ok();
+}
 
 // The extents reduce_layer_bucket() hands to RCCL for layer l, as offsets into the flat gradient buffer (host-side, for tests:
 // the buckets of all layers must tile [0, num_reduce) exactly once).  Returns the number of extents (<= 4).

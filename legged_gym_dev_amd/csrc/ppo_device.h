@@ -19,6 +19,11 @@ struct GemmArgs {                  // up to 2 problems per launch (actor, critic
     int Kpl[2], ldbpl[2];
     // weight gradient against the padded observations: N = padded width is computed, nstore (true width, row length of C) is stored
     int nstore[2];
+    // deterministic accumulation (lg_ppo_set_deterministic): C / colsum addresses inside [det_base, det_base + det_n) accumulate into
+    // det64 as 2^-40 fixed point instead (acc_add below); nullptr = float atomics
+    const float *det_base;
+    long long *det64;
+    int64_t det_n;
 };
 
 #define LG_PPO_MAX_SEG (2 * LG_PPO_MAX_LAYERS)
@@ -52,7 +57,31 @@ struct PpoDev {                    // passed by value to kernels
     int nseg;
     int64_t seg_off[LG_PPO_MAX_SEG], seg_pl[LG_PPO_MAX_SEG];
     int seg_rows[LG_PPO_MAX_SEG], seg_cols[LG_PPO_MAX_SEG];
+    // Deterministic mode (lg_ppo_set_deterministic; nullptr = off).  Every sum that many workgroups contribute to -- weight-gradient
+    // slices, bias column sums, the head's row sums, loss statistics, the gradient norm, the advantage moments -- is accumulated with
+    // float atomics, whose order differs from run to run.  With det64 set the same contributions are added as 2^-40 fixed-point
+    // 64-bit integers (integer addition is associative: any order gives the same bits) into a shadow of
+    // [grads (num_params + 2) | loss_acc (4) | adv_partial (4)], and k_det_fold adds the shadow into the float buffers before they are read.
+    long long *det64;
 };
+
+#define LG_DET_SCALE 1099511627776.0          // 2^40: |sum| < 2^23, resolution 9.1e-13
+__device__ __forceinline__ void det_add64(long long *q, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(q), (unsigned long long)__double2ll_rn((double)v * LG_DET_SCALE));
+}
+// atomicAdd(p, v) for p inside grads / loss_acc / adv_partial
+__device__ __forceinline__ void acc_add(const PpoDev &P, float *p, float v) {
+    if (!P.det64) { atomicAdd(p, v); return; }
+    long long i;
+    if (p >= P.grads && p < P.grads + P.num_params + 2) i = p - P.grads;
+    else if (p >= P.loss_acc && p < P.loss_acc + 4) i = P.num_params + 2 + (p - P.loss_acc);
+    else i = P.num_params + 6 + (p - P.adv_partial);
+    det_add64(P.det64 + i, v);
+}
+__device__ __forceinline__ void acc_add(const GemmArgs &g, float *p, float v) {
+    if (g.det64 && p >= g.det_base && p < g.det_base + g.det_n) det_add64(g.det64 + (p - g.det_base), v);
+    else atomicAdd(p, v);
+}
 
 // PPO.process_env_step for env i at rollout step t: rewards += gamma * V * time_outs ; store ; runner bookkeeping
 // (OnPolicyRunner.learn: cur_reward_sum / cur_episode_length / rewbuffer).  to: the env's extras["time_outs"] entry, or false.

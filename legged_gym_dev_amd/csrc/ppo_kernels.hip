@@ -663,13 +663,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, i
                         *cp = v;
                         csum += v;
                     } else {
-                        atomicAdd(cp, v);
+                        acc_add(g, cp, v);
                     }
                 }
             }
             if (EPI == 1 && g.colsum[z]) {
                 csum += __shfl_xor(csum, 32);
-                if (lk == 0) atomicAdd(&g.colsum[z][n], csum);
+                if (lk == 0) acc_add(g, &g.colsum[z][n], csum);
             }
         }
         return;
@@ -696,13 +696,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, i
                         C[(size_t)m * ldc + n] = v;
                         csum += v;
                     } else {
-                        atomicAdd(&C[(size_t)m * ldc + n], v);
+                        acc_add(g, &C[(size_t)m * ldc + n], v);
                     }
                 }
             }
         if (EPI == 1 && g.colsum[z]) {
             csum += __shfl_xor(csum, 32);
-            if (lk == 0 && n < N) atomicAdd(&g.colsum[z][n], csum);
+            if (lk == 0 && n < N) acc_add(g, &g.colsum[z][n], csum);
         }
     }
 }
@@ -1149,8 +1149,8 @@ __global__ void __launch_bounds__(256) k_gae(PpoDev P, const float *__restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        atomicAdd(&P.adv_partial[0], r1[0]);
-        atomicAdd(&P.adv_partial[1], r2[0]);
+        acc_add(P, &P.adv_partial[0], r1[0]);
+        acc_add(P, &P.adv_partial[1], r2[0]);
         if (blockIdx.x == 0) P.adv_partial[2] = (float)((size_t)N * T);
     }
 }
@@ -1318,29 +1318,27 @@ __global__ void __launch_bounds__(256) k_loss(PpoDev P, const float *__restrict_
         part[2 * MA + 2] = lv;
         part[2 * MA + 3] = fmaxf(s1, s2);
     }
-    // wave64 butterfly per partial, one LDS atomic per wave, one global atomic per block and partial
-    __shared__ float red[2 * MA + 4];
-    if (threadIdx.x < 2 * MA + 4) red[threadIdx.x] = 0.f;
-    __syncthreads();
+    // wave64 butterfly per partial, one LDS slot per wave (summed in wave order below), one global atomic per block and partial
+    __shared__ float red[4][2 * MA + 4];
 #pragma unroll
     for (int k = 0; k < 2 * MA + 4; ++k) {
         if (k >= 2 * MA || (k % MA) < A) {
             float v = part[k];
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], v);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
         }
     }
     __syncthreads();
     const int k = threadIdx.x;
     if (k < 2 * MA + 4 && (k >= 2 * MA || (k % MA) < A)) {
-        const float v = red[k];
-        if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
-        else if (k < 2 * MA) atomicAdd(&P.grads[P.off_bias_actor_head + (k - MA)], v);
-        else if (k == 2 * MA) atomicAdd(&P.grads[P.off_bias_critic_head], v);
-        else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);             // KL sum rides in the grad buffer tail
-        else if (k == 2 * MA + 2) atomicAdd(&P.loss_acc[0], v);
-        else atomicAdd(&P.loss_acc[1], v);
+        const float v = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+        if (k < MA) acc_add(P, &P.grads[P.off_std + k], v);
+        else if (k < 2 * MA) acc_add(P, &P.grads[P.off_bias_actor_head + (k - MA)], v);
+        else if (k == 2 * MA) acc_add(P, &P.grads[P.off_bias_critic_head], v);
+        else if (k == 2 * MA + 1) acc_add(P, &P.grads[P.num_params], v);             // KL sum rides in the grad buffer tail
+        else if (k == 2 * MA + 2) acc_add(P, &P.loss_acc[0], v);
+        else acc_add(P, &P.loss_acc[1], v);
     }
 }
 
@@ -1535,12 +1533,12 @@ __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__res
         const int k = tid;
         float v = 0.f;
         for (int r = 0; r < HEAD_ROWS; ++r) v += ptmp[k * HEAD_ROWS + r];
-        if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
-        else if (k < 2 * MA) atomicAdd(&P.grads[b_a + (k - MA)], v);
-        else if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
-        else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);
-        else if (k == 2 * MA + 2) atomicAdd(&P.loss_acc[0], v);
-        else atomicAdd(&P.loss_acc[1], v);
+        if (k < MA) acc_add(P, &P.grads[P.off_std + k], v);
+        else if (k < 2 * MA) acc_add(P, &P.grads[b_a + (k - MA)], v);
+        else if (k == 2 * MA) acc_add(P, &P.grads[b_c], v);
+        else if (k == 2 * MA + 1) acc_add(P, &P.grads[P.num_params], v);
+        else if (k == 2 * MA + 2) acc_add(P, &P.loss_acc[0], v);
+        else acc_add(P, &P.loss_acc[1], v);
     }
     float *acc = xa;                                      // reuse the tile buffer: [MA + 3][NH][H3]
     __syncthreads();
@@ -1556,10 +1554,10 @@ __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__res
         const int q = i / H3, cc = i % H3;
         float v = 0.f;
         for (int h = 0; h < NH; ++h) v += acc[(q * NH + h) * H3 + cc];
-        if (q < MA) { if (q < A) atomicAdd(&P.grads[w_a + (int64_t)q * H3 + cc], v); }
-        else if (q == MA) atomicAdd(&P.grads[w_c + cc], v);
-        else if (q == MA + 1) atomicAdd(&P.grads[b_prev_a + cc], v);
-        else atomicAdd(&P.grads[b_prev_c + cc], v);
+        if (q < MA) { if (q < A) acc_add(P, &P.grads[w_a + (int64_t)q * H3 + cc], v); }
+        else if (q == MA) acc_add(P, &P.grads[w_c + cc], v);
+        else if (q == MA + 1) acc_add(P, &P.grads[b_prev_a + cc], v);
+        else acc_add(P, &P.grads[b_prev_c + cc], v);
     }
 }
 
@@ -1797,18 +1795,18 @@ __global__ void __launch_bounds__(256) k_head_finish(PpoDev P, int nrows, int64_
     for (int r = r0; r < r1; ++r, src += HEAD_PART_STRIDE(H3)) v += *src;
     if (i < NW) {
         const int q = i / H3, cc = i % H3;
-        if (q < MA) atomicAdd(&P.grads[(actor ? w_a : w_c) + (int64_t)q * H3 + cc], v);
-        else atomicAdd(&P.grads[(actor ? b_prev_a : b_prev_c) + cc], v);
+        if (q < MA) acc_add(P, &P.grads[(actor ? w_a : w_c) + (int64_t)q * H3 + cc], v);
+        else acc_add(P, &P.grads[(actor ? b_prev_a : b_prev_c) + cc], v);
     } else {
         const int k = i - NW;
         if (actor) {
-            if (k < MA) atomicAdd(&P.grads[P.off_std + k], v);
-            else if (k < 2 * MA) atomicAdd(&P.grads[b_a + (k - MA)], v);
-            else if (k == 2 * MA + 1) atomicAdd(&P.grads[P.num_params], v);
-            else atomicAdd(&P.loss_acc[1], v);
+            if (k < MA) acc_add(P, &P.grads[P.off_std + k], v);
+            else if (k < 2 * MA) acc_add(P, &P.grads[b_a + (k - MA)], v);
+            else if (k == 2 * MA + 1) acc_add(P, &P.grads[P.num_params], v);
+            else acc_add(P, &P.loss_acc[1], v);
         } else {
-            if (k == 2 * MA) atomicAdd(&P.grads[b_c], v);
-            else atomicAdd(&P.loss_acc[0], v);
+            if (k == 2 * MA) acc_add(P, &P.grads[b_c], v);
+            else acc_add(P, &P.loss_acc[0], v);
         }
     }
 }
@@ -1851,7 +1849,19 @@ __global__ void __launch_bounds__(256) k_opt_prepare(PpoDev P, int par, int prep
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(&P.loss_acc[2 + par], red[0]);
+    if (threadIdx.x == 0) acc_add(P, &P.loss_acc[2 + par], red[0]);
+}
+// Deterministic mode: add the fixed-point shadow (PpoDev::det64) into the float buffers it stands for and clear it.  One adder per
+// element and launch, so the float result does not depend on the order the contributions arrived in.
+__global__ void __launch_bounds__(256) k_det_fold(PpoDev P) {
+    const int64_t n = P.num_params + 10;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long q = P.det64[i];
+        if (q == 0) continue;
+        float *t = i < P.num_params + 2 ? P.grads + i : i < P.num_params + 6 ? P.loss_acc + (i - P.num_params - 2) : P.adv_partial + (i - P.num_params - 6);
+        *t += (float)((double)q * (1.0 / LG_DET_SCALE));
+        P.det64[i] = 0;
+    }
 }
 // split-bf16 image of parameter k: pl_dest[k] = its element index inside a plane (weights) or -1 (biases, std)
 __device__ __forceinline__ void write_planes(const PpoDev &P, int64_t k, float x) {
@@ -1900,9 +1910,11 @@ void ppok_act_sample(const PpoDev *P, const float *obs, const float *cobs, const
 void ppok_process_step(const PpoDev *P, const float *rew, const uint8_t *dones, const uint8_t *tos, int t, hipStream_t s) {
     hipLaunchKernelGGL(k_process_step, dim3((P->N + 255) / 256), dim3(256), 0, s, *P, rew, dones, tos, t);
 }
+void ppok_det_fold(const PpoDev *P, hipStream_t s) { hipLaunchKernelGGL(k_det_fold, dim3(512), dim3(256), 0, s, *P); }
 void ppok_gae(const PpoDev *P, const float *last_values, hipStream_t s) {
     (void)hipMemsetAsync(P->adv_partial, 0, 3 * sizeof(float), s);
     hipLaunchKernelGGL(k_gae, dim3((P->N + 255) / 256), dim3(256), 0, s, *P, last_values);
+    if (P->det64) ppok_det_fold(P, s);
 }
 void ppok_adv_normalize(const PpoDev *P, hipStream_t s) {
     hipLaunchKernelGGL(k_adv_normalize, dim3(256), dim3(256), 0, s, *P);
@@ -1949,6 +1961,7 @@ int ppok_step(const PpoDev *P, int par, const PpoDev *G, int gather_mb, hipStrea
     const bool g4 = gather_mb >= 0 && (P->A & 3) == 0;
     const int gblocks = g4 ? (P->mb_rows * 32 + 255) / 256 : 0;
     hipLaunchKernelGGL(k_opt_prepare, dim3(128 + gblocks), dim3(256), 0, s, *P, par, 128, g4 ? *G : *P, gather_mb);
+    if (P->det64) ppok_det_fold(P, s);                   // the squared gradient norm
     // one parameter per thread: the per-parameter chain (4 loads, Adam, 4 stores + the three plane stores through pl_dest) is a
     // memory round trip that a grid-stride loop repeats serially (6 x for [512,256,128] on 256 workgroups: 12.2 us; 8.9 us on 1024, 10.2 on 2048)
     static const int adam_max = getenv("LG_ADAM_WGS") ? atoi(getenv("LG_ADAM_WGS")) : 1024;

@@ -62,6 +62,7 @@ def _declare_ppo(lib):
     lib.lg_ppo_end_update.argtypes = [vp]
     lib.lg_ppo_act_inference.argtypes = [vp, vp, vp, C.c_int64]
     lib.lg_ppo_params_changed.argtypes = [vp]
+    lib.lg_ppo_set_deterministic.argtypes = [vp, C.c_int]
     lib.lg_ppo_attach_env.argtypes = [vp, vp]
     lib.lg_ppo_debug_bucket_extents.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
 

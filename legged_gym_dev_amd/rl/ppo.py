@@ -5,6 +5,7 @@ reference tree; semantics per SURVEY.md Appendix B).  All tensors are zero-copy 
 library-owned HBM; every compute call is a C-ABI call -- there is no torch fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -101,6 +102,8 @@ class HipPPO:
         self._init_parameters(ah, ch)
         self.params_changed()
         self.use_current_stream()
+        if os.environ.get("LG_DETERMINISTIC", "0") not in ("", "0"):
+            self.set_deterministic(True)
 
     # nn.Linear default initialisation, drawn in the order rsl_rl's ActorCritic constructs its layers
     def _init_parameters(self, ah, ch):
@@ -177,6 +180,12 @@ class HipPPO:
     def attach_env(self, core):
         """lg_ppo_attach_env: ``core`` = the env's HipEnvCore (or None to detach, which runs whatever is still pending)."""
         self._call("attach_env", core.ctx if core is not None else None)
+
+    def set_deterministic(self, on=True):
+        """lg_ppo_set_deterministic: order-independent (fixed-point) accumulation of every cross-workgroup sum of the update, so
+        that two runs from one seed agree bit for bit (debugging aid: three extra small launches per optimiser step).  Also
+        switched on by LG_DETERMINISTIC=1 in the environment."""
+        self._call("set_deterministic", 1 if on else 0)
 
     def params_changed(self):
         """Call after writing parameters through ``param_views`` / ``t["params"]``: the rollout's weight images are re-derived

@@ -63,8 +63,51 @@ def learn_with_first_snapshot(runner, iters):
     return first
 
 
+class _TwinComm:
+    """ONE real rank standing for two identical ones: every collective goes through the process group (use_group) or is left
+    out, and the missing twin's contribution is added by hand.  Both variants compute the same numbers; only the first puts
+    torch.distributed's collectives -- RCCL when the group is "nccl" -- between the library's kernels on the learner's stream."""
+    rank, world_size, overlapped = 0, 2, False
+
+    def __init__(self, use_group):
+        self.use_group = use_group
+        self.calls = 0
+
+    def all_reduce(self, t):
+        if self.use_group:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+            self.calls += 1
+        t.mul_(2.0)
+
+    def broadcast(self, t, src=0):
+        if self.use_group:
+            torch.distributed.broadcast(t, src=src)
+
+
+def main_rccl_one_rank(outdir, task, n, iters):
+    """LG_TEST_MODE=rccl_one_rank: the default collective of the product (TorchDistComm's calls on an "nccl" = RCCL group) with
+    the only rank count a one-GPU box allows.  Writes the parameters after one iteration with and without the group."""
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    out = {}
+    for use in (True, False):
+        comm = _TwinComm(use)
+        env, runner = build(task, n, 0, 2, comm=comm)
+        assert runner.world_size == 2 and runner.comm is comm
+        out[f"params_it1_{'group' if use else 'plain'}"] = learn_with_first_snapshot(runner, iters)
+        out[f"fault_{'group' if use else 'plain'}"] = env.core.t["fault_total"].cpu().numpy()
+        if use:
+            out["calls"] = np.int64(comm.calls)
+        env.close()
+        runner.ppo.close()
+    np.savez(os.path.join(outdir, "rccl_one_rank.npz"), **out)
+    torch.distributed.destroy_process_group()
+
+
 def main():
     outdir, task, n, iters = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    if os.environ.get("LG_TEST_MODE") == "rccl_one_rank":
+        return main_rccl_one_rank(outdir, task, n, iters)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     torch.distributed.init_process_group("gloo")

@@ -153,6 +153,42 @@ def test_two_rank_runner_over_gloo(task, tmp_path):
     assert bad.mean() < 5e-3, bad.mean()
 
 
+def test_two_ranks_in_deterministic_mode_equal_the_emulation_bit_for_bit(tmp_path, monkeypatch):
+    """With LG_DETERMINISTIC=1 (lg_ppo_set_deterministic: fixed-point accumulation instead of float atomics) the comparison the
+    test above can only make to an order of magnitude becomes exact: two processes over gloo and the in-process emulation hold
+    the same parameters, Adam moments and learning rate after two iterations on rough terrain, bit for bit."""
+    monkeypatch.setenv("LG_DETERMINISTIC", "1")
+    n, iters = 64, 2
+    a, b = _run_ranks(tmp_path, "anymal_c_rough", n, iters)
+    emu = _emulate("anymal_c_rough", n, iters)
+    np.testing.assert_array_equal(a["params"], b["params"])
+    for key in ("params_it1", "params", "adam_m"):
+        np.testing.assert_array_equal(emu[0][key], a[key], err_msg=key)
+    assert float(emu[0]["lr"]) == float(a["lr"]) and float(emu[0]["adv_mean"]) == float(a["adv_mean"])
+    for r in range(2):
+        for key in ("obs", "root_states", "episode_length"):
+            np.testing.assert_array_equal(emu[r][key], (a, b)[r][key], err_msg=f"rank {r} {key}")
+
+
+def test_default_collective_over_rccl_with_one_rank(tmp_path):
+    """The product's default collective is torch.distributed on the "nccl" backend (= RCCL).  A one-GPU box allows one RCCL
+    rank: that rank runs the real runner with every all-reduce / broadcast going through the RCCL group on the learner's
+    stream, between the library's kernels, and must end where the same run without the group ends.  (More than one RCCL
+    rank has never run: DESIGN.md section 6.)"""
+    port = _free_port()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", LG_TEST_MODE="rccl_one_rank")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_rank_worker.py"), str(tmp_path), "anymal_c_flat", "64", "1"],
+                       env=env, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    r = dict(np.load(os.path.join(tmp_path, "rccl_one_rank.npz")))
+    a, b = r["params_it1_group"], r["params_it1_plain"]
+    assert int(r["calls"]) >= 21                         # one per optimiser step + the advantage moments
+    assert np.isfinite(a).all() and int(r["fault_group"][0]) == 0 and int(r["fault_plain"][0]) == 0
+    rel = np.linalg.norm(a - b) / np.linalg.norm(b)      # float-atomic noise of one iteration (see the gloo test below)
+    assert rel < 1e-5, rel
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` as the driver calls it (no torchrun): the parent starts one child per rank before it has
     made any GPU call; rank 0 prints the JSON line with n_gpus = 2.  Both ranks on cuda:0 over gloo here."""
