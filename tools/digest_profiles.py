@@ -17,7 +17,7 @@ def one(pattern):
     f = glob.glob(os.path.join(go, pattern))
     if not f:
         raise SystemExit(f"missing {pattern}")
-    return f[0]
+    return max(f, key=os.path.getmtime)            # gpurun merges into gpurun_out/: an earlier collection's files may still lie there
 
 
 stats = list(csv.DictReader(open(one(f"{tag}_prof/*/*kernel_stats.csv"))))

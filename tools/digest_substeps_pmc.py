@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-f = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_pmc_phys", "**", "*counter_collection.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_pmc_phys", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
     if "k_substeps" in r["Kernel_Name"]:
