@@ -140,30 +140,87 @@ class OnPolicyRunner:
                 ppo.attach_env(None)
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        """rsl_rl's OnPolicyRunner.learn: rollout, update, one log block per iteration, checkpoints every save_interval.
+
+        The log block needs a handful of device values (episode ring, losses, lr, std, per-term episode sums).  Fetching and
+        printing them between iterations leaves the GPU idle for ~1 ms of every 14 (tools/cpu_enqueue_time.py), so by default the
+        iteration's values go out as ONE packed asynchronous copy at the end of its update, its phase times come from HIP events
+        on the learner's stream, and its block is printed while the GPU is already working on the next iteration: the host never
+        waits for an idle GPU.  LG_LOG_SYNC=1 (and any wandb_callback, which is handed live parameters) keeps rsl_rl's
+        synchronise-measure-print order."""
         env, ppo = self.env, self.ppo
         if init_at_random_ep_len:
             env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
         tot_iter = self.current_learning_iteration + num_learning_iterations
+        deferred = self.wandb_callback is None and os.environ.get("LG_LOG_SYNC", "0") in ("", "0")
+        pending = []
+
+        def flush():
+            while pending:
+                self._log(*pending.pop(0))
+
         for it in range(self.current_learning_iteration, tot_iter):
-            torch.cuda.synchronize()
-            start = time.time()
-            self.rollout()
-            torch.cuda.synchronize()
-            stop = time.time()
-            collection_time = stop - start
-            start = stop
-            mean_value_loss, mean_surrogate_loss = ppo.update(self._grad_reduce)
-            torch.cuda.synchronize()
-            learn_time = time.time() - start
-            self._log(it, tot_iter, collection_time, learn_time, float(mean_value_loss), float(mean_surrogate_loss))
+            if deferred:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                self.rollout()
+                ev[1].record()
+                losses = ppo.update(self._grad_reduce)
+                ev[2].record()
+                pending.append((it, tot_iter, ev, self._log_snapshot(*losses)))
+                while len(pending) > 1:                  # the previous iteration's block, beside this iteration's GPU work
+                    self._log(*pending.pop(0))
+            else:
+                torch.cuda.synchronize()
+                start = time.time()
+                self.rollout()
+                torch.cuda.synchronize()
+                stop = time.time()
+                losses = ppo.update(self._grad_reduce)
+                torch.cuda.synchronize()
+                self._log(it, tot_iter, (stop - start, time.time() - stop), self._log_snapshot(*losses))
             if self.log_dir is not None and self.rank == 0 and it % self.save_interval == 0:
+                flush()
                 self.save(os.path.join(self.log_dir, f"model_{it}.pt"))
+        flush()
+        torch.cuda.synchronize()
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None and self.rank == 0:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 
-    def _log(self, it, tot_iter, collection_time, learn_time, vloss, sloss, width=80, pad=35):
+    def _log_snapshot(self, vloss, sloss):
+        """Everything one log block reads from the device, as one float64 vector copied to pinned host memory without blocking
+        (layout: episode ring 200 | episodes finished | mean std | learner stats 8 | losses 2 | per-term episode sums + step count |
+        physics faults); the per-iteration accumulators are cleared behind the copy, in stream order.  Returns (host vector, event)."""
+        ppo, t = self.ppo, self.env.core.t
+        parts = [ppo.t["ep_ring"].reshape(-1), ppo.t["ep_ring_count"].reshape(-1)[:1], ppo.param_views["std"].mean().reshape(1),
+                 ppo.t["stats"].reshape(-1)[:8], vloss.reshape(1), sloss.reshape(1), t["extras_episode_acc"].reshape(-1),
+                 t["fault_total"].reshape(-1)[:1]]
+        dev = torch.cat([p.to(torch.float64) for p in parts])
+        if getattr(self, "_log_host", None) is None or self._log_host[0].numel() != dev.numel():
+            self._log_host = [torch.empty(dev.numel(), dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._log_flip = 0
+        host = self._log_host[self._log_flip]
+        self._log_flip ^= 1
+        host.copy_(dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        ppo.t["ep_stats"].zero_()
+        t["extras_episode_acc"].zero_()
+        return host, done, int(t["extras_episode_acc"].numel())
+
+    def _log(self, it, tot_iter, times, snap, width=80, pad=35):
         ppo = self.ppo
+        host, done, nacc = snap
+        done.synchronize()
+        if isinstance(times, list):                       # HIP events on the learner's stream (all three have completed by now)
+            collection_time, learn_time = times[0].elapsed_time(times[1]) * 1e-3, times[1].elapsed_time(times[2]) * 1e-3
+        else:
+            collection_time, learn_time = times
+        v = host.tolist()
+        ring, cnt, mean_std, stats = v[:200], int(v[200]) & 0xFFFFFFFF, v[201], v[202:210]
+        vloss, sloss, acc, faults = v[210], v[211], v[212:212 + nacc], int(v[212 + nacc])
+        lr = stats[0]
         steps = self.num_steps_per_env * self.env.num_envs * self.world_size
         self.tot_timesteps += steps
         self.tot_time += collection_time + learn_time
@@ -172,14 +229,9 @@ class OnPolicyRunner:
         # rsl_rl bookkeeping, kept on the device by k_process_step / k_finalize and fetched once per iteration:
         # rewbuffer / lenbuffer = the last 100 finished episodes; ep_infos = infos["episode"] of every step, averaged
         # (the device counter is a free-running uint32: slot = count % 100; once 100 episodes have finished the ring stays full)
-        ring, cnt = ppo.t["ep_ring"].cpu(), int(ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
         self._ring_full = getattr(self, "_ring_full", False) or cnt >= 100
         k = 100 if self._ring_full else cnt
-        self.rewbuffer, self.lenbuffer = deque(ring[0, :k].tolist(), maxlen=100), deque(ring[1, :k].tolist(), maxlen=100)
-        ppo.t["ep_stats"].zero_()
-        mean_std = float(ppo.param_views["std"].mean())
-        acc = self.env.core.t["extras_episode_acc"].cpu()
-        self.env.core.t["extras_episode_acc"].zero_()
+        self.rewbuffer, self.lenbuffer = deque(ring[:k], maxlen=100), deque(ring[100:100 + k], maxlen=100)
         nsteps = max(float(acc[-1]), 1.0)
         ep = {}
         rows = self.env.setup.term_row
@@ -188,13 +240,12 @@ class OnPolicyRunner:
                 ep[name] = float(acc[_NUM_TERMS]) / nsteps
             elif name.startswith("rew_") and name[4:] in rows:
                 ep[name] = float(acc[rows[name[4:]]]) / nsteps
-        faults = int(self.env.core.t["fault_total"].cpu())
         if self.rank != 0:
             return
         lines = [f" Learning iteration {it}/{tot_iter} ".center(width, " "), "",
                  f"{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {collection_time:.3f}s, learning {learn_time:.3f}s)",
                  f"{'Value function loss:':>{pad}} {vloss:.4f}", f"{'Surrogate loss:':>{pad}} {sloss:.4f}",
-                 f"{'Mean action noise std:':>{pad}} {mean_std:.2f}", f"{'Learning rate:':>{pad}} {ppo.learning_rate:.2e}"]
+                 f"{'Mean action noise std:':>{pad}} {mean_std:.2f}", f"{'Learning rate:':>{pad}} {lr:.2e}"]
         if self.rewbuffer:
             lines += [f"{'Mean reward:':>{pad}} {statistics.mean(self.rewbuffer):.2f}",
                       f"{'Mean episode length:':>{pad}} {statistics.mean(self.lenbuffer):.2f}"]
@@ -208,7 +259,7 @@ class OnPolicyRunner:
             locs = {"mean_value_loss": vloss, "mean_surrogate_loss": sloss, "rewbuffer": self.rewbuffer,
                     "lenbuffer": self.lenbuffer, "ep_infos": [ep] if ep else [], "it": it,
                     "collection_time": collection_time, "learn_time": learn_time, "tot_iter": tot_iter}
-            self.wandb_callback(locs, ppo.learning_rate, mean_std, self.alg.actor_critic.state_dict(),
+            self.wandb_callback(locs, lr, mean_std, self.alg.actor_critic.state_dict(),
                                 ppo.optimizer_state_dict(), self.device, 0)
 
     # ------------------------------------------------------------------ checkpoints
