@@ -4,6 +4,7 @@
 // reference tree; call sites legged_gym/utils/task_registry.py:148-155).
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "ppo_device.h"
 
@@ -219,6 +220,12 @@ __device__ __forceinline__ void gemm_mainloop(const float *__restrict__ A, const
 // four different bank phases while fragment reads (32 consecutive rows) stay conflict-free.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define X6_ROWB 80
+#ifndef LG_GEMM_STEADY              // compile-time A/B: 1 = steady-state loop with unconditional prefetch (forward / input gradient)
+#define LG_GEMM_STEADY 0
+#endif
+#ifndef LG_DW_STEADY                // the same for the weight-gradient kernel
+#define LG_DW_STEADY 0
+#endif
 // Workgroup barrier of the GEMM mainloops: LDS traffic only.  __syncthreads() carries workgroup-scope fences, for which hipcc drains
 // EVERY outstanding memory operation (s_waitcnt vmcnt(0)) -- including the global loads issued two k-tiles ahead, whose latency
 // the prefetch distance exists to hide.  The mainloops exchange data through LDS alone: waiting for this wave's LDS operations
@@ -447,12 +454,18 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
         }
     };
 
-    // one k-tile: x = the set holding tile k0 + BK (stored to LDS after the MFMAs), y = the set tile k0 + PD BK is loaded into
-    auto body = [&](int k0, Regs &x, Regs &y, int st) {
+    // one k-tile: x = the set holding tile k0 + BK (stored to LDS after the MFMAs), y = the set tile k0 + PD BK is loaded into.
+    // steady = std::true_type: both exist (the caller checked), so the loads and the store are UNCONDITIONAL.  hipcc counts
+    // s_waitcnt vmcnt per path and takes the minimum where paths join: with the prefetch under `if (k0 + PD BK < k_end)` the
+    // store of tile k0 + BK -- whose loads are a whole iteration old -- waited as if the prefetch had not been issued, i.e. until the
+    // loads issued a few hundred cycles earlier had landed (vmcnt(3)..(0) instead of (8)..(5) in the ISA): every k-tile exposed a
+    // memory round trip behind its MFMA block.  The steady-state loop below has no such join; the last 2 PD - 1 tiles run the guarded form.
+    auto body = [&](auto steady, int k0, Regs &x, Regs &y, int st) {
+        constexpr bool ST = decltype(steady)::value;
         const int so = LDB ? st * STAGE : 0;                     // stage the MFMAs of this k-tile read
-        if (k0 + PD * BK < k_end) load_tile(y, k0 + PD * BK);
+        if (ST || k0 + PD * BK < k_end) load_tile(y, k0 + PD * BK);
         if constexpr (LDB) {
-            if (k0 + BK < k_end) store_tile(x, st ^ 1);
+            if (ST || k0 + BK < k_end) store_tile(x, st ^ 1);
         }
         bf16x8 av[2][TM][3], bv[2][TN][3];
 #pragma unroll
@@ -494,14 +507,20 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
         }
         if constexpr (!LDB) {
             lds_barrier();                     // every wave is done reading before the tile is refilled
-            if (k0 + BK < k_end) store_tile(x, 0);
+            if (ST || k0 + BK < k_end) store_tile(x, 0);
         }
         lds_barrier();
     };
-    for (int k0 = k_begin; k0 < k_end; k0 += PD * BK) {
+    int k0 = k_begin;
+    if (LG_GEMM_STEADY)
+        for (; k0 + (2 * PD - 1) * BK < k_end; k0 += PD * BK) {      // every tile of the group has its successor and its prefetch target
+#pragma unroll
+            for (int d = 0; d < PD; ++d) body(std::true_type{}, k0 + d * BK, R[(d + 1) % PD], R[d], d & 1);
+        }
+    for (; k0 < k_end; k0 += PD * BK) {
 #pragma unroll
         for (int d = 0; d < PD; ++d)
-            if (d == 0 || k0 + d * BK < k_end) body(k0 + d * BK, R[(d + 1) % PD], R[d], d & 1);
+            if (d == 0 || k0 + d * BK < k_end) body(std::false_type{}, k0 + d * BK, R[(d + 1) % PD], R[d], d & 1);
     }
 }
 
@@ -663,7 +682,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, i
                         *cp = v;
                         csum += v;
                     } else {
+#ifdef LG_EXP_NO_DW_ATOMICS                                           // timing experiment only (make exp): what the split-K atomics cost
+                        asm volatile("" :: "v"(v), "v"(cp));
+#elif defined(LG_EXP_DW_PLAIN_STORE)                                  // timing experiment only: plain stores of the same bytes
+                        *cp = v;
+#else
                         acc_add(g, cp, v);
+#endif
                     }
                 }
             }
@@ -843,7 +868,10 @@ __device__ __forceinline__ void stage_store_x6t(unsigned char *__restrict__ lds,
     }
 }
 
-template <int TM, int TN, int WGM, int WGN>
+// PD: k-tiles of global loads in flight per workgroup (register sets).  3 and 4 measured no faster for the first layer's thin
+// gradient (42.8 / 56.9 vs 42.4 us: the fourth set costs a workgroup per CU) and slower for the 128 x 128 tiles (spills at 128 VGPRs);
+// neither were 128 x 64 tiles or 96 reduction slices for that launch (profiles/r03_ab.txt).
+template <int TM, int TN, int WGM, int WGN, int PD = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm_dw_t(GemmArgs g) {
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN, NT = 64 * WGM * WGN;
     constexpr int APL = plt_plane_bytes<BM>(), BPL = plt_plane_bytes<BN>();
@@ -890,59 +918,81 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm
     };
     const bool a_vec = (lda & 3) == 0 && ((uintptr_t)A & 15) == 0 && (M & 3) == 0 && M >= 4;
     const bool b_vec = (ldb & 3) == 0 && ((uintptr_t)B & 15) == 0 && (N & 3) == 0 && N >= 4;
-    float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
-    unsigned ma0, mb0, ma1 = 0, mb1 = 0;
-    auto load = [&](int k0, float4 (&ra)[NVA], float4 (&rb)[NVB], unsigned &ma, unsigned &mb) {
-        if (a_vec) stage_load<false, BM, true, false, NT>(A, lda, m0, k0, M, k_end, ra, ma);
-        else stage_load<false, BM, false, false, NT>(A, lda, m0, k0, M, k_end, ra, ma);
-        if (b_vec) stage_load<false, BN, true, false, NT>(B, ldb, n0, k0, N, k_end, rb, mb);
-        else stage_load<false, BN, false, false, NT>(B, ldb, n0, k0, N, k_end, rb, mb);
-    };
-    load(k_begin, ra0, rb0, ma0, mb0);
-    if (k_begin + BK < k_end) load(k_begin + BK, ra1, rb1, ma1, mb1);
-    stage_store_x6t<BM, NT>(lds, ra0, ma0);
-    stage_store_x6t<BN, NT>(lds_b, rb0, mb0);
-    lds_barrier();
-    auto body = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb, float4 (&ya)[NVA], float4 (&yb)[NVB],
-                    unsigned &yma, unsigned &ymb) {
-        if (k0 + 2 * BK < k_end) load(k0 + 2 * BK, ya, yb, yma, ymb);     // two k-tiles ahead, into the set just consumed
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 av[TM][3], bv[TN][3];
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) av[a][p] = frag(fa, 512 * a + p * APL + (BM / 32 * 512) * 2 * s);
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bv[b][p] = frag(fb, 512 * b + p * BPL + (BN / 32 * 512) * 2 * s);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    const bf16x8 *x = av[a], *y = bv[b];
-                    f32x16 c = acc[a][b];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
-                    acc[a][b] = c;
-                }
-        }
+    // The whole k-loop once per load form (16-byte loads for both operands, or the element-wise fallback): with the choice as a
+    // branch INSIDE the loop hipcc's s_waitcnt insertion lost track of the prefetched registers across the join -- in the
+    // steady-state loop below the split read a register set with no vmcnt wait at all (wrong sums), in the guarded form it
+    // waited for everything.
+    auto run = [&](auto vec) {
+        constexpr bool VEC = decltype(vec)::value;
+        float4 ra[PD][NVA], rb[PD][NVB];
+        unsigned ma[PD], mb[PD];
+    #pragma unroll
+        for (int d = 0; d < PD; ++d) { ma[d] = 0u; mb[d] = 0u; }
+        auto load = [&](int k0, float4 (&xa)[NVA], float4 (&xb)[NVB], unsigned &xma, unsigned &xmb) {
+            stage_load<false, BM, VEC, false, NT>(A, lda, m0, k0, M, k_end, xa, xma);
+            stage_load<false, BN, VEC, false, NT>(B, ldb, n0, k0, N, k_end, xb, xmb);
+        };
+    #pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d == 0 || k_begin + d * BK < k_end) load(k_begin + d * BK, ra[d], rb[d], ma[d], mb[d]);
+        stage_store_x6t<BM, NT>(lds, ra[0], ma[0]);
+        stage_store_x6t<BN, NT>(lds_b, rb[0], mb[0]);
         lds_barrier();
-        if (k0 + BK < k_end) {
-            stage_store_x6t<BM, NT>(lds, xa, xma);
-            stage_store_x6t<BN, NT>(lds_b, xb, xmb);
+        // one k-tile (in LDS; its register set c is free): loads of tile + PD into set c, MFMAs, then the next tile (set n) to LDS
+        // steady: unconditional prefetch and store (see gemm_mainloop_x6: a guarded prefetch makes the store wait for it)
+        auto body = [&](auto steady, int k0, float4 (&ca)[NVA], float4 (&cb)[NVB], unsigned &cma, unsigned &cmb, float4 (&na)[NVA], float4 (&nb)[NVB],
+                        unsigned &nma, unsigned &nmb) {
+            constexpr bool ST = decltype(steady)::value;
+            if (ST || k0 + PD * BK < k_end) load(k0 + PD * BK, ca, cb, cma, cmb);
+    #pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                bf16x8 av[TM][3], bv[TN][3];
+    #pragma unroll
+                for (int a = 0; a < TM; ++a)
+    #pragma unroll
+                    for (int p = 0; p < 3; ++p) av[a][p] = frag(fa, 512 * a + p * APL + (BM / 32 * 512) * 2 * s);
+    #pragma unroll
+                for (int b = 0; b < TN; ++b)
+    #pragma unroll
+                    for (int p = 0; p < 3; ++p) bv[b][p] = frag(fb, 512 * b + p * BPL + (BN / 32 * 512) * 2 * s);
+    #pragma unroll
+                for (int a = 0; a < TM; ++a)
+    #pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const bf16x8 *x = av[a], *y = bv[b];
+                        f32x16 c = acc[a][b];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
+                        acc[a][b] = c;
+                    }
+            }
+            lds_barrier();
+            if (ST || k0 + BK < k_end) {
+                stage_store_x6t<BM, NT>(lds, na, nma);
+                stage_store_x6t<BN, NT>(lds_b, nb, nmb);
+            }
+            lds_barrier();
+        };
+        int k0 = k_begin;
+        if (LG_DW_STEADY)
+            for (; k0 + (2 * PD - 1) * BK < k_end; k0 += PD * BK) {
+    #pragma unroll
+                for (int d = 0; d < PD; ++d)
+                    body(std::true_type{}, k0 + d * BK, ra[d], rb[d], ma[d], mb[d], ra[(d + 1) % PD], rb[(d + 1) % PD], ma[(d + 1) % PD], mb[(d + 1) % PD]);
+            }
+        for (; k0 < k_end; k0 += PD * BK) {
+    #pragma unroll
+            for (int d = 0; d < PD; ++d)
+                if (d == 0 || k0 + d * BK < k_end)
+                    body(std::false_type{}, k0 + d * BK, ra[d], rb[d], ma[d], mb[d], ra[(d + 1) % PD], rb[(d + 1) % PD], ma[(d + 1) % PD], mb[(d + 1) % PD]);
         }
-        lds_barrier();
     };
-    for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
-        body(k0, ra1, rb1, ma1, mb1, ra0, rb0, ma0, mb0);
-        if (k0 + BK < k_end) body(k0 + BK, ra0, rb0, ma0, mb0, ra1, rb1, ma1, mb1);
-    }
+    if (a_vec && b_vec) run(std::true_type{});
+    else run(std::false_type{});
     // nstore: columns past it are products with the zero pad columns of the padded observations -- computed, not stored
     gemm_epilogue<2, TM, TN, BM, BN, 1>(g, z, M, g.nstore[z] ? g.nstore[z] : N, m0, n0, wm, wn, li, lk, ldc, acc);
 }

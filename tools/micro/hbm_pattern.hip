@@ -1,0 +1,79 @@
+// HBM read bandwidth of the access patterns the thin GEMM launches use, against a linear stream (MI355X).
+//   linear : every workgroup streams a contiguous chunk, float4 per lane, DEPTH loads in flight per lane
+//   tile   : the first layer's weight-gradient pattern -- a [M x 512] fp32 matrix, workgroup (column tile of 64, row slice of 512):
+//            per step 32 rows x 256 B (stride 2 KB), 2 float4 per lane, DEPTH steps in flight
+//   hipcc --offload-arch=gfx950 -O3 hbm_pattern.hip -o _bin/hbm_pattern
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+template <int DEPTH>
+__global__ void __launch_bounds__(256) k_linear(const float4 *__restrict__ src, float *__restrict__ out, size_t n4_per_wg) {
+    const float4 *p = src + (size_t)blockIdx.x * n4_per_wg + threadIdx.x;
+    float s = 0.f;
+    for (size_t i = 0; i < n4_per_wg; i += 256 * DEPTH) {
+        float4 v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) v[d] = p[i + 256 * d];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) s += v[d].x + v[d].y + v[d].z + v[d].w;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int DEPTH>
+__global__ void __launch_bounds__(256) k_tile(const float *__restrict__ src, float *__restrict__ out, int ld, int rows_per_slice) {
+    // blockIdx.x = column tile (64 floats), blockIdx.y = row slice
+    const int c4 = threadIdx.x & 15, r = threadIdx.x >> 4;                  // 16 float4 per row segment, 16 rows per pass, 2 passes per step
+    const float *base = src + (size_t)blockIdx.y * rows_per_slice * ld + blockIdx.x * 64 + 4 * c4;
+    float s = 0.f;
+    for (int k0 = 0; k0 < rows_per_slice; k0 += 32 * DEPTH) {
+        float4 v[DEPTH][2];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) v[d][h] = *reinterpret_cast<const float4 *>(base + (size_t)(k0 + 32 * d + 16 * h + r) * ld);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) s += v[d][h].x + v[d][h].y + v[d][h].z + v[d][h].w;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
+template <typename F>
+static float time_ms(F launch) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch();
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    return best;
+}
+
+int main() {
+    const int M = 24576 * 4, LD = 512;                        // 201 MB: larger than L2 + MALL
+    const size_t bytes = (size_t)M * LD * 4;
+    float *src, *out; (void)hipMalloc(&src, bytes); (void)hipMalloc(&out, 64); (void)hipMemset(src, 0, bytes);
+    {
+        const int wgs = 3072; const size_t n4 = bytes / 16 / wgs;
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_linear<2>, dim3(wgs), dim3(256), 0, 0, (const float4 *)src, out, n4); });
+        printf("linear, 2 float4 in flight per lane, %d workgroups: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_linear<4>, dim3(wgs), dim3(256), 0, 0, (const float4 *)src, out, n4); });
+        printf("linear, 4 float4 in flight per lane, %d workgroups: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_linear<8>, dim3(wgs), dim3(256), 0, 0, (const float4 *)src, out, n4); });
+        printf("linear, 8 float4 in flight per lane, %d workgroups: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+    }
+    for (int slices : {48 * 4, 96 * 4, 192 * 4}) {
+        const int rps = M / slices;
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_tile<1>, dim3(LD / 64, slices), dim3(256), 0, 0, src, out, LD, rps); });
+        printf("tile 32 x 256 B, 1 step in flight,  %4d workgroups of %4d rows: %6.1f us  %5.2f TB/s\n", 8 * slices, rps, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_tile<2>, dim3(LD / 64, slices), dim3(256), 0, 0, src, out, LD, rps); });
+        printf("tile 32 x 256 B, 2 steps in flight, %4d workgroups of %4d rows: %6.1f us  %5.2f TB/s\n", 8 * slices, rps, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_tile<4>, dim3(LD / 64, slices), dim3(256), 0, 0, src, out, LD, rps); });
+        printf("tile 32 x 256 B, 4 steps in flight, %4d workgroups of %4d rows: %6.1f us  %5.2f TB/s\n", 8 * slices, rps, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}
