@@ -413,9 +413,18 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     Regs R[PD];
     unsigned char *lds_b = lds + 3 * APL;
     auto load_tile = [&](Regs &r, int k) {
+#ifdef LG_EXP_A_SAME_TILE           // timing experiment only (make exp): every k-tile re-reads the first A tile (cache hits instead of HBM)
+        stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k_begin, M, k_end, r.a, r.ma);
+#else
         stage_load<A_RC, BM, VEC, true, NT, FULL>(A, lda, m0, k, M, k_end, r.a, r.ma);
+#endif
+#ifdef LG_EXP_B_SAME_TILE           // timing experiment only: the same for the weight-plane tile
+        if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, r.p, r.mb);
+        else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k_begin, N, k_end, r.p, r.mb);
+#else
         if constexpr (B_PL == 2) stage_load_plt<BN, NT>(Bpl, pl_stride, ldb, n0, k, N, k_end, r.p, r.mb);
         else if constexpr (B_PL == 1) stage_load_pl<BN, NT>(Bpl, pl_stride, ldb, n0, k, N, k_end, r.p, r.mb);
+#endif
         else stage_load<B_RC, BN, VEC, true, NT, FULL>(B, ldb, n0, k, N, k_end, r.b, r.mb);
     };
     constexpr int STAGE = 3 * APL + 3 * BPL;                     // bytes of one LDS stage

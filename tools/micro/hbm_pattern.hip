@@ -40,6 +40,28 @@ __global__ void __launch_bounds__(256) k_tile(const float *__restrict__ src, flo
     if (s == 123.456f) out[0] = s;
 }
 
+// the forward GEMM's A-tile pattern: [M x 512] fp32, workgroup = 128 rows; per step SEG bytes of each row (8 or 16 lanes x 16 B per row,
+// the rest of the wave on further rows), walking along the row: 128 B per row and step = a BK of 32, 256 B = 64
+template <int SEG, int DEPTH>
+__global__ void __launch_bounds__(512) k_rowseg(const float *__restrict__ src, float *__restrict__ out, int ld) {
+    constexpr int LPR = SEG / 16, RPP = 512 / LPR, PASSES = 128 / RPP;       // lanes per row, rows per pass, passes per step
+    const int c = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const float *base = src + (size_t)blockIdx.x * 128 * ld + 4 * c;
+    float s = 0.f;
+    for (int k0 = 0; k0 < ld * 4; k0 += SEG * DEPTH) {
+        float4 v[DEPTH][PASSES];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) v[d][p] = *reinterpret_cast<const float4 *>(base + (size_t)(p * RPP + r) * ld + (k0 + d * SEG) / 4);
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) s += v[d][p].x + v[d][p].y + v[d][p].z + v[d][p].w;
+    }
+    if (s == 123.456f) out[0] = s;
+}
+
 template <typename F>
 static float time_ms(F launch) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -74,6 +96,17 @@ int main() {
         printf("tile 32 x 256 B, 2 steps in flight, %4d workgroups of %4d rows: %6.1f us  %5.2f TB/s\n", 8 * slices, rps, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
         ms = time_ms([&] { hipLaunchKernelGGL(k_tile<4>, dim3(LD / 64, slices), dim3(256), 0, 0, src, out, LD, rps); });
         printf("tile 32 x 256 B, 4 steps in flight, %4d workgroups of %4d rows: %6.1f us  %5.2f TB/s\n", 8 * slices, rps, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+    }
+    {
+        const int wgs = M / 128;
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_rowseg<128, 1>), dim3(wgs), dim3(512), 0, 0, src, out, LD); });
+        printf("128 rows x 128 B per step, 1 step in flight,  %d workgroups of 512: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_rowseg<128, 2>), dim3(wgs), dim3(512), 0, 0, src, out, LD); });
+        printf("128 rows x 128 B per step, 2 steps in flight, %d workgroups of 512: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_rowseg<256, 1>), dim3(wgs), dim3(512), 0, 0, src, out, LD); });
+        printf("128 rows x 256 B per step, 1 step in flight,  %d workgroups of 512: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_rowseg<256, 2>), dim3(wgs), dim3(512), 0, 0, src, out, LD); });
+        printf("128 rows x 256 B per step, 2 steps in flight, %d workgroups of 512: %6.1f us  %5.2f TB/s\n", wgs, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
     }
     return 0;
 }
