@@ -718,6 +718,59 @@ int lg_ppo_debug_bucket_extents(lg_ppo *p, int l, int64_t *offsets, int64_t *cou
     return n;
 }
 
+// Timing experiment (tools/graph_period.py): the period of {minibatch_backward(mb 0), minibatch_step} launched `reps` times back to back on a
+// stream of its own -- directly, or as ONE captured hipGraph replayed `reps` times (the fork onto the side stream and the join become graph
+// edges).  Call inside an update (after lg_ppo_begin_update).  The repeated step reuses one gradient-norm slot, so the numbers the update
+// produces are meaningless; the launches, their sizes and their dependencies are the real ones.
+int lg_ppo_debug_graph_period(lg_ppo *p, int reps, int use_graph, float *us_out) {
+    hipStream_t s = nullptr, old = p->stream;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { lg_set_error("stream create failed"); return -100; }
+    (void)hipStreamSynchronize(old);
+    p->stream = s;
+    const int ga = p->gather_ahead;
+    p->gather_ahead = 0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    int rc = 0;
+    auto one = [&]() { rc |= lg_ppo_minibatch_backward(p, 0, 0); rc |= lg_ppo_minibatch_step(p); p->update_count--; };
+    one();                                                     // warm-up (also leaves grads_dirty = 0)
+    (void)hipStreamSynchronize(s);
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeGlobal) != hipSuccess) { lg_set_error("begin capture failed"); rc = -100; }
+        else {
+            one();
+            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                lg_set_error(std::string("graph capture / instantiate failed: ") + hipGetErrorString(hipGetLastError())); rc = -100;
+            }
+        }
+        if (!rc) { (void)hipGraphLaunch(exec, s); (void)hipStreamSynchronize(s); }
+    }
+    if (!rc) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < reps; ++i) {
+            if (use_graph) (void)hipGraphLaunch(exec, s);
+            else one();
+        }
+        (void)hipEventRecord(e1, s);
+        (void)hipStreamSynchronize(s);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *us_out = ms * 1e3f / (float)reps;
+    }
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(s);
+    if (p->side) (void)hipStreamSynchronize(p->side);
+    p->stream = old;
+    p->gather_ahead = ga;
+    p->mb_ready = -1;
+    (void)hipStreamDestroy(s);
+    return rc ? rc : launch_ok();
+}
+
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows) {
     if (rows > p->Mmax) { lg_set_error("too many rows for act_inference"); return -11; }
     forward(p, (int)rows, obs, nullptr, 1);
