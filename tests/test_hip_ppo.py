@@ -652,3 +652,52 @@ def test_early_first_layer_weight_gradient_equals_the_tail_launch(O):
         assert float((a - ref).norm() / ref.norm()) < 3e-4
     finally:
         hip.close()
+
+
+def test_optimiser_step_equals_torch_adam_with_clip_and_adaptive_lr():
+    """Known-answer test of lg_ppo_minibatch_step ("Adam step vs torch.optim.Adam"): the SAME gradients are written into
+    the library's gradient buffer and into torch parameters' .grad; `clip_grad_norm_(max_grad_norm)` + `torch.optim.Adam.step()` with
+    rsl_rl's KL-adaptive learning rate applied by hand must land on the library's parameters and Adam moments to float rounding, over
+    six steps that exercise: clipping on / off, lr up (KL < desired / 2), lr down (KL > 2 desired), lr unchanged."""
+    N, O, A, T = 64, 48, 12, 8
+    pol = dict(POLICY, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32])
+    hip, ac, pt = _make(N, O, A, T, pol)
+    n = hip.num_params
+    params = list(ac.parameters())                      # std, actor..., critic...: the flat buffer's order
+    assert sum(p.numel() for p in params) == n
+    lr = 1e-3
+    opt = torch.optim.Adam(params, lr=lr)
+    hip._call("begin_update")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rows = T * N // ALG["num_mini_batches"]
+    cases = [(5.0, 0.010), (0.01, 0.010), (0.3, 0.001), (0.3, 0.050), (2.0, 0.004), (0.02, 0.030)]   # (gradient scale, mean KL)
+    for scale, kl in cases:
+        grad = torch.randn(n, device="cuda", generator=g) * scale / n ** 0.5
+        hip.t["grads"][:n].copy_(grad)
+        hip.t["grads"][n] = kl * rows                   # the KL SUM of the minibatch rides behind the gradients
+        if kl > 0.01 * 2.0:
+            lr = max(1e-5, lr / 1.5)
+        elif 0.0 < kl < 0.01 / 2.0:
+            lr = min(1e-2, lr * 1.5)
+        for pg in opt.param_groups:
+            pg["lr"] = lr
+        off = 0
+        for p in params:
+            p.grad = grad[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        total = torch.nn.utils.clip_grad_norm_(params, ALG["max_grad_norm"])
+        opt.step()
+        hip._call("minibatch_step")
+        torch.cuda.synchronize()
+        assert (float(total) > 1.0) == (scale >= 2.0)   # the cases on either side of the clip threshold are what they claim
+        ref = pt.flat_params(ac)
+        torch.testing.assert_close(hip.t["params"][:n], ref, rtol=3e-6, atol=1e-7)   # a step is lr ~ 1e-3: 1e-4 of a step
+        assert abs(hip.learning_rate - lr) <= 3e-7 * lr                     # the library keeps lr as fp32 in HBM
+        assert float(hip.t["grads"][: n + 2].abs().max()) == 0.0            # the step leaves the gradient buffer cleared
+    st = opt.state_dict()["state"]
+    m = torch.cat([st[i]["exp_avg"].reshape(-1) for i in range(len(params))])
+    v = torch.cat([st[i]["exp_avg_sq"].reshape(-1) for i in range(len(params))])
+    # (the norm is reduced in another order, so the clip coefficient may differ by an ulp: absolute band = rounding at the moments' scale)
+    torch.testing.assert_close(hip.t["adam_m"][:n], m, rtol=3e-6, atol=1e-6 * float(m.abs().max()))
+    torch.testing.assert_close(hip.t["adam_v"][:n], v, rtol=3e-6, atol=1e-6 * float(v.abs().max()))
+    hip.close()
