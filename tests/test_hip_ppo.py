@@ -7,6 +7,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
 POLICY = {"actor_hidden_dims": [512, 256, 128], "critic_hidden_dims": [512, 256, 128], "activation": "elu",
           "init_noise_std": 1.0}
 ALG = dict(value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2, entropy_coef=0.01,
@@ -700,4 +705,74 @@ def test_optimiser_step_equals_torch_adam_with_clip_and_adaptive_lr():
     # (the norm is reduced in another order, so the clip coefficient may differ by an ulp: absolute band = rounding at the moments' scale)
     torch.testing.assert_close(hip.t["adam_m"][:n], m, rtol=3e-6, atol=1e-6 * float(m.abs().max()))
     torch.testing.assert_close(hip.t["adam_v"][:n], v, rtol=3e-6, atol=1e-6 * float(v.abs().max()))
+    hip.close()
+
+
+def test_gae_kernel_on_the_hand_computed_example():
+    """The hand-computed GAE example that pins the torch restatement (tests/test_ppo_oracle.py: 3 steps x 2 envs, a done in the middle of
+    env 0, gamma 0.9, lambda 0.5) through the LIBRARY: rewards / values / dones written into the rollout storage, the bootstrap values
+    (1, -1) produced by a critic wired to return obs[0] - 3, then lg_ppo_compute_returns + lg_ppo_normalize_advantages."""
+    N, O, A, T = 2, 48, 12, 3
+    alg = dict(ALG, gamma=0.9, lam=0.5, num_mini_batches=2)
+    pol = dict(POLICY, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32])
+    hip, ac, pt = _make(N, O, A, T, pol, alg)
+    for k, v in hip.param_views.items():
+        if k.startswith("critic."):
+            v.zero_()
+    for name in ("critic.0.weight", "critic.2.weight", "critic.4.weight"):
+        hip.param_views[name][0, 0] = 1.0                                 # obs[0] > 0 passes the ELU layers unchanged
+    hip.param_views["critic.4.bias"][0] = -3.0
+    hip.params_changed()
+    hip.t["rewards"].copy_(torch.tensor([[1.0, 2.0], [0.5, -1.0], [2.0, 0.0]]))
+    hip.t["values"].copy_(torch.tensor([[0.5, 1.0], [1.5, 0.0], [-0.5, 2.0]]))
+    hip.t["dones"].copy_(torch.tensor([[0, 0], [1, 0], [0, 0]], dtype=torch.uint8))
+    last_obs = torch.zeros(N, O, device="cuda")
+    last_obs[:, 0] = torch.tensor([4.0, 2.0])                             # V(s_T) = 1, -1
+    hip._call("compute_returns", ctypes_ptr(last_obs))
+    torch.cuda.synchronize()
+    g, l = 0.9, 0.5
+    a2 = 2.0 + g * 1.0 - (-0.5)
+    a1 = 0.5 + 0.0 - 1.5                                                  # done at t = 1 cuts the bootstrap and the trace
+    a0 = 1.0 + g * 1.5 - 0.5 + g * l * a1
+    b2 = 0.0 + g * (-1.0) - 2.0
+    b1 = -1.0 + g * 2.0 - 0.0 + g * l * b2
+    b0 = 2.0 + g * 0.0 - 1.0 + g * l * b1
+    adv = torch.tensor([[a0, b0], [a1, b1], [a2, b2]], device="cuda")
+    torch.testing.assert_close(hip.t["returns"], adv + hip.t["values"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(hip.t["advantages"], adv, rtol=1e-6, atol=1e-6)        # raw until normalize_advantages
+    hip._call("normalize_advantages")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(hip.t["advantages"], (adv - adv.mean()) / (adv.std() + 1e-8), rtol=1e-5, atol=1e-6)
+    hip.close()
+
+
+@pytest.mark.parametrize("sign,expected", [(1.0, (-0.7 - 1.0 - 1.2) / 3), (-1.0, (0.8 + 1.0 + 1.3) / 3)])
+def test_clipped_surrogate_and_kl_known_answers_through_the_library(sign, expected):
+    """The known-answer cases that pin the torch restatement (tests/test_ppo_oracle.py) through the LIBRARY's loss path: three rows whose
+    importance ratios are 0.7, 1.0, 1.3 (the stored log-prob shifted by -ln r), advantages +1 (then -1), clip 0.2:
+    mean surrogate = mean max(-A r, -A clip(r, 0.8, 1.2)); the KL of a policy with itself = sum_a ln(1 + 1e-5) (rsl_rl's epsilon inside the
+    log); value loss 0 when returns = values."""
+    N, O, A, T = 3, 48, 12, 1
+    alg = dict(ALG, num_mini_batches=1, num_learning_epochs=1)
+    pol = dict(POLICY, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32])
+    hip, ac, pt = _make(N, O, A, T, pol, alg)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = torch.randn(N, O, device="cuda", generator=g)
+    hip.inject_noise(1)
+    hip.t["noise"].zero_()                                                 # a = mu
+    hip.act(obs)
+    hip.process_env_step(torch.zeros(N, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"), {})
+    torch.cuda.synchronize()
+    ratios = torch.tensor([0.7, 1.0, 1.3], device="cuda")
+    hip.t["log_prob"].view(-1).sub_(torch.log(ratios))                      # exp(lp_new - lp_old) = r
+    hip.t["advantages"].fill_(sign)
+    hip.t["returns"].copy_(hip.t["values"])
+    hip._call("begin_update")
+    hip._call("minibatch_backward", 0, 0)
+    hip._call("minibatch_step")
+    torch.cuda.synchronize()
+    st = hip.stats()
+    assert abs(st["surrogate_loss_sum"] / st["n_updates"] - expected) < 2e-6, st
+    assert abs(st["value_loss_sum"]) < 1e-10, st
+    assert abs(st["kl"] - A * np.log1p(1e-5)) < 2e-7, st
     hip.close()
