@@ -1026,3 +1026,45 @@ def test_trajectory_task_trains_through_the_registry(tmp_path):
         runner.ppo.close()
     finally:
         env.close()
+
+
+class _HipBackend:
+    """What tests/test_physics_oracle.py calls `oracle_built`, backed by the HIP library instead: the invariants below then check the
+    product physics against physics itself (a float64 mass-matrix formulation, conservation laws, statics), with no oracle in between."""
+
+    @staticmethod
+    def OracleEnv(setup, height_samples=None):
+        return harness.HipHandle(setup, height_samples)
+
+
+@pytest.mark.parametrize("robot", ["anymal_c", "cassie", "a1"])
+def test_hip_free_dynamics_match_mass_matrix_formulation(robot):
+    """One substep of lg_simulate in free flight == M(q) nu_dot + h(q, nu) = tau built from link Jacobians in float64 (an independent
+    formulation: no articulated-body recursion), for the quadruped and the biped topology kernels."""
+    from tests import test_physics_oracle as tpo
+    tpo.test_free_dynamics_match_mass_matrix_formulation(robot, _HipBackend)
+
+
+def test_hip_momentum_conserved_without_gravity():
+    from tests import test_physics_oracle as tpo
+    tpo.test_momentum_conserved_without_gravity(_HipBackend)
+
+
+@pytest.mark.parametrize("robot,height", [("anymal_c", 0.56), ("cassie", 0.95), ("a1", 0.36)])
+def test_hip_static_stance_supports_weight(robot, height):
+    """PD-held stance on the plane through lg_compute_torques + lg_simulate: the vertical contact forces add up to the robot's weight,
+    every foot carries load, the base stays put."""
+    from tests import test_physics_oracle as tpo
+    tpo.test_static_stance_supports_weight(robot, height, _HipBackend)
+
+
+@pytest.mark.parametrize("robot", ["a1", "cassie"])
+def test_hip_joint_limits_hold_against_torque(robot):
+    from tests import test_physics_oracle as tpo
+    tpo.test_joint_limits_hold_against_torque(robot, _HipBackend)
+
+
+def test_hip_shape_material_parameters_act_on_the_contacts():
+    """Restitution / compliance / thickness of the randomised rigid-shape properties (legged_robot.py:284-299) as the HIP contact model carries them."""
+    from tests import test_physics_oracle as tpo
+    tpo.test_shape_material_parameters_act_on_the_contacts(_HipBackend)
