@@ -1068,3 +1068,63 @@ def test_hip_shape_material_parameters_act_on_the_contacts():
     """Restitution / compliance / thickness of the randomised rigid-shape properties (legged_robot.py:284-299) as the HIP contact model carries them."""
     from tests import test_physics_oracle as tpo
     tpo.test_shape_material_parameters_act_on_the_contacts(_HipBackend)
+
+
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough", "cassie"])
+def test_product_env_matches_oracle_at_baseline_size(task, oracle_built):
+    """BASELINE.json configs[1], [2], [4] at their FULL size: the product env (task_registry.make_env: 4096 envs, for the rough tasks the
+    reference's 10 x 20 tile terrain of 1300 x 2100 height samples) against the oracle built from the same EnvSetup and height field,
+    with the product's per-env constants copied over.  reset() and then 6 policy steps on the built-in Philox streams with episode
+    clocks scattered over time-outs, command resamples and the push period: reset / time-out masks, episode lengths, terrain levels and
+    the reset count bit-exact on all 4096 envs, fp32 state / observations / rewards / height scans within the per-step tolerance (the
+    two trajectories are glued together after every step: contacts amplify fp32 rounding)."""
+    import torch
+    n = 4096
+    env = _product_env(task, n, terrain=None)
+    ora = oracle_built.OracleEnv(env.setup, env.terrain.heightsamples if env.terrain is not None else None)
+    hip = harness.HipHandle.__new__(harness.HipHandle)           # the adapter around the product env's own context
+    hip.torch, hip.core, hip.setup, hip._act = torch, env.core, env.setup, None
+    try:
+        for key in ("env_origins", "friction", "base_mass_delta", "material", "terrain_levels", "terrain_types", "root_states"):
+            ora.set(key, hip.get(key))
+        rng = np.random.default_rng(7)
+        A = env.num_actions
+        for e in (hip, ora):
+            e.set_step_counter(0)
+            e.inject(0)
+            e.set_init_done(1)
+            e.call("reset_all")
+        np.testing.assert_allclose(hip.get("root_states"), ora.get("root_states"), rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(hip.get("terrain_levels"), ora.get("terrain_levels"))
+        ep = rng.integers(0, int(env.max_episode_length), n)
+        ep[:8] = [199, 499, int(env.max_episode_length) - 1, int(env.max_episode_length), int(env.max_episode_length) + 1, 399, 0, 1]
+        push = int(env.setup.push_time) if env.setup.push_time else 0
+        for e in (hip, ora):
+            e.set("episode_length", ep)
+            e.set_step_counter(max(push - 3, 0))                  # a push falls inside the window where the task pushes
+        resets = 0
+        for t in range(6):
+            act = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+            hip.step(act)
+            ora.step(act)
+            np.testing.assert_array_equal(hip.get("reset"), ora.get("reset"), err_msg=f"step {t} reset")
+            np.testing.assert_array_equal(hip.get("time_out"), ora.get("time_out"), err_msg=f"step {t} time_out")
+            np.testing.assert_array_equal(hip.get("episode_length"), ora.get("episode_length"))
+            np.testing.assert_array_equal(hip.get("terrain_levels"), ora.get("terrain_levels"), err_msg=f"step {t} terrain_levels")
+            assert int(hip.get("n_reset")[0]) == int(ora.get("n_reset")[0])
+            resets += int(ora.get("n_reset")[0])
+            keys = [("obs", 2e-3), ("rew", 2e-3), ("root_states", 1e-3), ("dof_state", 2e-3), ("commands", 1e-6), ("torques", 5e-3)]
+            if env.setup.num_height_points:
+                keys.append(("measured_heights", 1e-6))
+            for key, tol in keys:
+                a, b = hip.get(key), ora.get(key)
+                bad = ~np.isclose(a, b, rtol=tol, atol=tol)
+                # a contact that opens or closes one substep apart moves a joint rate by more than the band: a handful of envs per step
+                assert bad.reshape(n, -1).any(1).sum() <= (0 if key in ("commands", "measured_heights") else 8), (t, key, int(bad.sum()))
+            for key in ("root_states", "dof_state", "lstm_h", "lstm_c", "last_dof_vel", "last_root_vel", "feet_air_time", "episode_sums",
+                        "last_actions", "last_contacts", "commands"):
+                hip.set(key, ora.get(key))
+        assert resets > 0 and int(hip.get("fault_total")[0]) == 0
+    finally:
+        ora.close()
+        env.close()
