@@ -119,11 +119,24 @@ def test_philox_sampling_is_standard_normal():
 
 @pytest.mark.parametrize("O,hidden", [(48, None), (235, None), (169, None), (65, None), (48, [128, 64, 32])])
 def test_returns_and_gradients_match_torch(O, hidden):
+    _returns_and_gradients(O, hidden, 512, 8)
+
+
+@pytest.mark.parametrize("O", [48, 235])
+def test_returns_and_gradients_match_torch_at_baseline_size(O):
+    """The same comparison at BASELINE.json's size: 4096 envs x 24 steps, minibatches of 24 576 rows through [512,256,128] (flat and rough
+    observation widths): returns / advantages against the restatement, the gradients of two minibatches against autograd."""
+    # (gradients are means over 24 576 rows here: more first-layer weights sit within 10x of Adam's eps, where a step follows the
+    # gradient's size -- the share of parameters outside the post-step band is asserted at 0.2 % instead of 0.05 %)
+    _returns_and_gradients(O, None, 4096, 24, band_frac=2e-3)
+
+
+def _returns_and_gradients(O, hidden, N, T, band_frac=5e-4):
     """O: the observation widths of the four tasks.  235, 169 and 65 are not multiples of 8: the minibatch gathers and the
     first layer's weight planes then carry zero pad columns (rows of 240 / 176 / 72) and the first layer's weight gradient is
     computed on the padded width and stored on the true one.  hidden = [128, 64, 32]: the reference's own flat-task policy
     (anymal_c_flat_config.py:62-65), whose 32-wide last hidden layer takes the k_head_fused<32> path."""
-    N, A, T = 512, 12, 8
+    A = 12
     pol = POLICY if hidden is None else dict(POLICY, actor_hidden_dims=hidden, critic_hidden_dims=hidden)
     hip, ac, pt = _make(N, O, A, T, pol)
     g = torch.Generator(device="cuda").manual_seed(2)
@@ -190,11 +203,12 @@ def test_returns_and_gradients_match_torch(O, hidden):
         # are < 0.05 % of them, and none is off by more than the two sign steps taken so far.
         got_p, ref_p = hip.t["params"][: hip.num_params], pt.flat_params(ac)
         bad = (got_p - ref_p).abs() > (2e-6 + 1e-4 * ref_p.abs())
-        assert float(bad.float().mean()) < 5e-4, float(bad.float().mean())
+        assert float(bad.float().mean()) < band_frac, float(bad.float().mean())
         assert float((got_p - ref_p).abs().max()) <= 2.1 * algo.learning_rate * (mb + 1)
         if mb == 0 and bool(bad.any()):                    # (after the first step the Adam moments carry step 0's noise as well)
             gerr, gmag = (g_got - g_ref).abs()[bad], g_ref.abs()[bad]
-            explained = (gerr >= 0.02 * gmag) | (gmag <= 1e-6 * scale)
+            # ... or a gradient within 10x of Adam's eps (1e-8), where the step lr g / (|g| + eps) follows the gradient's SIZE
+            explained = (gerr >= 0.02 * gmag) | (gmag <= 1e-6 * scale) | (gmag <= 1e-7)
             assert bool(explained.all()), (int((~explained).sum()), int(bad.sum()))
     hip.close()
 
