@@ -1070,7 +1070,7 @@ def test_hip_shape_material_parameters_act_on_the_contacts():
     tpo.test_shape_material_parameters_act_on_the_contacts(_HipBackend)
 
 
-@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough", "cassie"])
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_flat_trajectory"])
 def test_product_env_matches_oracle_at_baseline_size(task, oracle_built):
     """BASELINE.json configs[1], [2], [4] at their FULL size: the product env (task_registry.make_env: 4096 envs, for the rough tasks the
     reference's 10 x 20 tile terrain of 1300 x 2100 height samples) against the oracle built from the same EnvSetup and height field,
@@ -1085,8 +1085,9 @@ def test_product_env_matches_oracle_at_baseline_size(task, oracle_built):
     hip = harness.HipHandle.__new__(harness.HipHandle)           # the adapter around the product env's own context
     hip.torch, hip.core, hip.setup, hip._act = torch, env.core, env.setup, None
     try:
-        for key in ("env_origins", "friction", "base_mass_delta", "material", "terrain_levels", "terrain_types", "root_states"):
-            ora.set(key, hip.get(key))
+        for key in ora.buf:                                       # whatever the product env's constructor put into its context
+            if key in hip.core.t:
+                ora.set(key, hip.get(key))
         rng = np.random.default_rng(7)
         A = env.num_actions
         for e in (hip, ora):
@@ -1116,13 +1117,18 @@ def test_product_env_matches_oracle_at_baseline_size(task, oracle_built):
             keys = [("obs", 2e-3), ("rew", 2e-3), ("root_states", 1e-3), ("dof_state", 2e-3), ("commands", 1e-6), ("torques", 5e-3)]
             if env.setup.num_height_points:
                 keys.append(("measured_heights", 1e-6))
+            if env.setup.traj:                                     # the trajectory generator's state and the tracked window
+                keys += [("trajectory", 1e-5), ("tg_traj", 1e-5), ("prev_error", 1e-4), ("push_timer", 1e-6)]
             for key, tol in keys:
                 a, b = hip.get(key), ora.get(key)
                 bad = ~np.isclose(a, b, rtol=tol, atol=tol)
                 # a contact that opens or closes one substep apart moves a joint rate by more than the band: a handful of envs per step
-                assert bad.reshape(n, -1).any(1).sum() <= (0 if key in ("commands", "measured_heights") else 8), (t, key, int(bad.sum()))
-            for key in ("root_states", "dof_state", "lstm_h", "lstm_c", "last_dof_vel", "last_root_vel", "feet_air_time", "episode_sums",
-                        "last_actions", "last_contacts", "commands"):
+                assert bad.reshape(n, -1).any(1).sum() <= (0 if key in ("commands", "measured_heights", "push_timer") else 8), (t, key, int(bad.sum()))
+            glue = ["root_states", "dof_state", "lstm_h", "lstm_c", "last_dof_vel", "last_root_vel", "feet_air_time", "episode_sums",
+                    "last_actions", "last_contacts", "commands"]
+            if env.setup.traj:
+                glue += ["tg_state", "tg_traj", "trajectory", "prev_error", "push_timer"]
+            for key in glue:
                 hip.set(key, ora.get(key))
         assert resets > 0 and int(hip.get("fault_total")[0]) == 0
     finally:
