@@ -505,9 +505,11 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
                 for (int b = 0; b < TN; ++b) {
                     const bf16x8 *x = av[s & 1][a], *y = bv[s & 1][b];
                     f32x16 c = acc[a][b];                 // smallest terms first
+#ifndef LG_EXP_THREE_PRODUCTS        // timing experiment only (make exp): what a three-product scheme (two-term fp16 split) would execute
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+#endif
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
@@ -612,9 +614,11 @@ __device__ __forceinline__ void gemm_mainloop_x6_pp(const float *__restrict__ A,
                 for (int b = 0; b < TN; ++b) {
                     const bf16x8 *x = av[s & 1][a], *y = bv[s & 1][b];
                     f32x16 c = acc[a][b];                 // smallest terms first
+#ifndef LG_EXP_THREE_PRODUCTS        // timing experiment only (make exp): what a three-product scheme (two-term fp16 split) would execute
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+#endif
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
