@@ -260,3 +260,47 @@ def test_deterministic_mode_reproduces_training_bit_for_bit(case):
     n = a["first"].numel() - 2
     rel = float((c["first"][:n] - a["first"][:n]).norm() / a["first"][:n].norm())
     assert rel < 1e-5, rel
+
+
+def test_deferred_log_blocks_equal_the_synchronous_ones(monkeypatch, capsys):
+    """OnPolicyRunner.learn prints iteration k's block while the GPU works on iteration k + 1 (values from one packed asynchronous copy,
+    phase times from HIP events); LG_LOG_SYNC=1 keeps rsl_rl's synchronise - measure - print order.  In deterministic mode the two must
+    print the same blocks, line for line, apart from the three timing lines -- same losses, learning rate, std, episode statistics,
+    per-term episode sums, step totals -- one block per iteration, in order."""
+    import copy
+    from legged_gym_dev_amd.envs import task_registry
+    from legged_gym_dev_amd.rl.runner import OnPolicyRunner
+    from legged_gym_dev_amd.utils.helpers import class_to_dict
+    monkeypatch.setenv("LG_DETERMINISTIC", "1")
+
+    def blocks(sync):
+        monkeypatch.setenv("LG_LOG_SYNC", "1" if sync else "0")
+        task = "anymal_c_rough"
+        args = _args(task, 256)
+        env_cfg, train_cfg = (copy.deepcopy(c) for c in task_registry.get_cfgs(task))
+        env_cfg.env.num_envs = 256
+        env_cfg.terrain.num_rows, env_cfg.terrain.num_cols, env_cfg.terrain.border_size = 4, 8, 5
+        env_cfg.terrain.max_init_terrain_level = 3
+        train_cfg.policy.actor_hidden_dims = train_cfg.policy.critic_hidden_dims = [64, 32]
+        env, _ = task_registry.make_env(name=task, args=args, env_cfg=env_cfg)
+        torch.manual_seed(5)
+        runner = OnPolicyRunner(env, class_to_dict(train_cfg), None, device="cuda:0")
+        capsys.readouterr()
+        try:
+            runner.learn(4, init_at_random_ep_len=True)
+            runner.learn(1)
+        finally:
+            env.close()
+            runner.ppo.close()
+        out = capsys.readouterr().out
+        keep = [ln for ln in out.splitlines() if not any(k in ln for k in ("Computation:", "Iteration time:", "Total time:"))]
+        assert sum("Learning iteration" in ln for ln in keep) == 5
+        return keep, runner.tot_timesteps
+
+    a, na = blocks(False)
+    b, nb = blocks(True)
+    assert na == nb == 5 * 24 * 256
+    assert a == b
+    assert any("Mean reward:" in ln for ln in a) and any("Mean episode terrain_level:" in ln for ln in a)
+    assert [ln.strip() for ln in a if "Learning iteration" in ln] == ["Learning iteration 0/4", "Learning iteration 1/4", "Learning iteration 2/4",
+                                                                        "Learning iteration 3/4", "Learning iteration 4/5"]
