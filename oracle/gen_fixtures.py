@@ -784,6 +784,22 @@ def main():
     rsp.randomize_restitution = rsp.randomize_compliance = rsp.randomize_thickness = True
     make_case(ref, "anymal_c_randomised", "anymal_c", cfg, ref["Anymal"], 2, 20, "default")
 
+    # yaw-rate commands (heading_command off: the third resample draw is the yaw rate itself, legged_robot.py:416-420), no observation
+    # noise, decimation 2 with the actuator net (two LSTM evaluations and physics sub-steps per policy step; dt = 0.01: other
+    # episode length, resample and push periods), tracking rewards live
+    cfg = ref["AnymalCFlatCfg"]()
+    cfg.env.num_envs = 32
+    cfg.commands.heading_command = False
+    cfg.commands.ranges.lin_vel_x = [-1.0, 1.0]
+    cfg.commands.ranges.lin_vel_y = [-0.5, 0.5]
+    cfg.commands.ranges.ang_vel_yaw = [-1.5, 1.5]
+    cfg.commands.resampling_time = 0.1
+    cfg.control.decimation = 2
+    cfg.noise.add_noise = False
+    cfg.rewards.scales.tracking_lin_vel = 1.0
+    cfg.rewards.scales.tracking_ang_vel = 0.5
+    make_case(ref, "anymal_c_yawcmd", "anymal_c", cfg, ref["Anymal"], 4, 21, "default")
+
     lstm_fixture()
 
 

@@ -18,7 +18,7 @@ from legged_gym_dev_amd.model.robot_model import compile_model, resolve_model  #
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 FIXTURES = ["anymal_c_flat", "anymal_c_rough", "cassie", "anymal_c_allrewards", "anymal_c_pd_V", "anymal_c_pd_T", "a1", "anymal_b",
-            "anymal_c_flat_curriculum", "anymal_c_randomised"]
+            "anymal_c_flat_curriculum", "anymal_c_randomised", "anymal_c_yawcmd"]
 
 
 def load_fixture(name):
@@ -54,6 +54,15 @@ def make_cfg(name):
         cfg.domain_rand.randomize_inv_base_mass = True
         rsp = cfg.domain_rand.rigid_shape_properties
         rsp.randomize_restitution = rsp.randomize_compliance = rsp.randomize_thickness = True
+    elif name == "anymal_c_yawcmd":                       # yaw-rate commands, no observation noise, decimation 2
+        cfg = AnymalCFlatCfg()
+        cfg.env.num_envs = 32
+        cfg.commands.heading_command = False
+        cfg.commands.ranges.lin_vel_x, cfg.commands.ranges.lin_vel_y, cfg.commands.ranges.ang_vel_yaw = [-1.0, 1.0], [-0.5, 0.5], [-1.5, 1.5]
+        cfg.commands.resampling_time = 0.1
+        cfg.control.decimation = 2
+        cfg.noise.add_noise = False
+        cfg.rewards.scales.tracking_lin_vel, cfg.rewards.scales.tracking_ang_vel = 1.0, 0.5
     elif name == "anymal_c_rough":
         cfg = AnymalCRoughCfg()
         cfg.env.num_envs = 64
