@@ -353,13 +353,20 @@ __device__ __forceinline__ void stage_store_pl(unsigned char *__restrict__ lds, 
 // chunk XOR of cdna_hip_programming.md T10 image (a): off(row, ch) = GRP (row>>3) + 512 (ch>>2) + 64 (row&7) +
 // 16 ((ch&3) ^ ((row>>2)&3)), ch = 16-byte chunk of the row, GRP = 512 BN/32 -- conflict-free for both the b128 stores'
 // rows and the transposed reads.
+// Subtile stride PLT_SUB = 512 + 64 bytes (LG_PLT_SUB): with subtiles exactly 512 B apart the 4 (stores of 16 B: 16 lanes, stores of 8 B: 32
+// lanes) subtiles one k-row spans fall on the SAME 16 banks -- a 4-way conflict on every staging store (SQ_LDS_BANK_CONFLICT = 17 % of the LDS
+// cycles of the input-gradient kernel, 29-33 % of the weight-gradient kernels': profiles/r03_kernel_clocks.txt).  The 64-byte pad rotates
+// them onto the four quarters of the bank row; a transposed read stays inside one subtile and is unaffected.
+#ifndef LG_PLT_SUB
+#define LG_PLT_SUB 576
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int BN>
 __device__ __forceinline__ int plt_off(int row, int ch) {
-    return (BN / 32 * 512) * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+    return (BN / 32 * LG_PLT_SUB) * (row >> 3) + LG_PLT_SUB * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 template <int BN>
-constexpr int plt_plane_bytes() { return BK * BN * 2; }
+constexpr int plt_plane_bytes() { return BK / 8 * (BN / 32) * LG_PLT_SUB; }
 
 template <int BN, int NT>
 __device__ __forceinline__ void stage_load_plt(const uint16_t *__restrict__ src, int64_t pl_stride, int ld, int n0, int red0, int ncols,
@@ -449,11 +456,11 @@ __device__ __forceinline__ void gemm_mainloop_x6(const float *__restrict__ A, co
     const unsigned char *ft[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-        ft[h] = lds_b + (BN / 32 * 512) * (tg >> 1) + 512 * (wn / 32) + 64 * (4 * h + tq) +
+        ft[h] = lds_b + (BN / 32 * LG_PLT_SUB) * (tg >> 1) + LG_PLT_SUB * (wn / 32) + 64 * (4 * h + tq) +
                 16 * ((2 * (tg & 1) + (tp >> 1)) ^ (2 * (tg >> 1) + h)) + 8 * (tp & 1);
     auto read_b = [&](int b, int p, int s, int so) -> bf16x8 {
         if constexpr (B_PL == 2) {
-            const int o = so + 512 * b + p * BPL + (BN / 32 * 512) * 2 * s;
+            const int o = so + LG_PLT_SUB * b + p * BPL + (BN / 32 * LG_PLT_SUB) * 2 * s;
             const s16x4 lo = lds_read_tr16(ft[0] + o), hi = lds_read_tr16(ft[1] + o);
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -572,11 +579,11 @@ __device__ __forceinline__ void gemm_mainloop_x6_pp(const float *__restrict__ A,
     const unsigned char *ft[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-        ft[h] = lds_b + (BN / 32 * 512) * (tg >> 1) + 512 * (wn / 32) + 64 * (4 * h + tq) +
+        ft[h] = lds_b + (BN / 32 * LG_PLT_SUB) * (tg >> 1) + LG_PLT_SUB * (wn / 32) + 64 * (4 * h + tq) +
                 16 * ((2 * (tg & 1) + (tp >> 1)) ^ (2 * (tg >> 1) + h)) + 8 * (tp & 1);
     auto read_b = [&](int b, int p, int s) __attribute__((always_inline)) -> bf16x8 {
         if constexpr (B_PL == 2) {
-            const int o = 512 * b + p * BPL + (BN / 32 * 512) * 2 * s;
+            const int o = LG_PLT_SUB * b + p * BPL + (BN / 32 * LG_PLT_SUB) * 2 * s;
             const s16x4 lo = lds_read_tr16(ft[0] + o), hi = lds_read_tr16(ft[1] + o);
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -920,8 +927,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int lane_off = 64 * (4 * h + tq) + 16 * ((2 * (tg & 1) + (tp >> 1)) ^ (2 * (tg >> 1) + h)) + 8 * (tp & 1);
-        fa[h] = lds + (BM / 32 * 512) * (tg >> 1) + 512 * (wm / 32) + lane_off;
-        fb[h] = lds_b + (BN / 32 * 512) * (tg >> 1) + 512 * (wn / 32) + lane_off;
+        fa[h] = lds + (BM / 32 * LG_PLT_SUB) * (tg >> 1) + LG_PLT_SUB * (wm / 32) + lane_off;
+        fb[h] = lds_b + (BN / 32 * LG_PLT_SUB) * (tg >> 1) + LG_PLT_SUB * (wn / 32) + lane_off;
     }
     auto frag = [&](const unsigned char *const (&f)[2], int o) -> bf16x8 {
         const s16x4 lo = lds_read_tr16(f[0] + o), hi = lds_read_tr16(f[1] + o);
@@ -963,11 +970,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 4 : 2) k_gemm
     #pragma unroll
                 for (int a = 0; a < TM; ++a)
     #pragma unroll
-                    for (int p = 0; p < 3; ++p) av[a][p] = frag(fa, 512 * a + p * APL + (BM / 32 * 512) * 2 * s);
+                    for (int p = 0; p < 3; ++p) av[a][p] = frag(fa, LG_PLT_SUB * a + p * APL + (BM / 32 * LG_PLT_SUB) * 2 * s);
     #pragma unroll
                 for (int b = 0; b < TN; ++b)
     #pragma unroll
-                    for (int p = 0; p < 3; ++p) bv[b][p] = frag(fb, 512 * b + p * BPL + (BN / 32 * 512) * 2 * s);
+                    for (int p = 0; p < 3; ++p) bv[b][p] = frag(fb, LG_PLT_SUB * b + p * BPL + (BN / 32 * LG_PLT_SUB) * 2 * s);
     #pragma unroll
                 for (int a = 0; a < TM; ++a)
     #pragma unroll
