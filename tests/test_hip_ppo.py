@@ -127,8 +127,8 @@ def test_returns_and_gradients_match_torch_at_baseline_size(O):
     """The same comparison at BASELINE.json's size: 4096 envs x 24 steps, minibatches of 24 576 rows through [512,256,128] (flat and rough
     observation widths): returns / advantages against the restatement, the gradients of two minibatches against autograd."""
     # (gradients are means over 24 576 rows here: more first-layer weights sit within 10x of Adam's eps, where a step follows the
-    # gradient's size -- the share of parameters outside the post-step band is asserted at 0.2 % instead of 0.05 %)
-    _returns_and_gradients(O, None, 4096, 24, band_frac=2e-3)
+    # gradient's size -- the share of parameters outside the post-step band, 0.1 % measured, is asserted at 0.4 % instead of 0.05 %)
+    _returns_and_gradients(O, None, 4096, 24, band_frac=4e-3)
 
 
 def _returns_and_gradients(O, hidden, N, T, band_frac=5e-4):
