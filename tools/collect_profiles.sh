@@ -19,6 +19,11 @@ R="--task anymal_c_rough"
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_anymal_c_rough_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $R $B > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_anymal_c_rough_pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 $R $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_anymal_c_rough_pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 $R $B > /dev/null 2>&1
+# BASELINE configs[4]: the biped on the same terrain (169 observations, 2 x 6 kinematic tree, PD law)
+R="--task cassie"
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_cassie_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $R $B > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_cassie_pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 $R $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_cassie_pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 $R $B > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 # keep what travels back small: the counter / trace CSVs only
 find gpurun_out/${TAG}_*prof gpurun_out/${TAG}_*pmc_* -type f ! -name "*.csv" -delete 2>/dev/null
