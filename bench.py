@@ -206,12 +206,23 @@ def env_roofline(env, reps=50):
            "hbm": {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                    "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP}}
     if pmc:
-        valu, cycles = pmc["critical_wave_valu_per_lg_step"], 4.0 * pmc["lg_step"]["wave_quad_cycles"]
-        clock = cycles / (ms_loop * 1e-3)                            # Hz the kernel's waves saw (DVFS: well under the 2.4 GHz peak)
-        out.update({"achieved": round(valu / (ms_loop * 1e-3) / 1e6, 1), "peak": round(clock / 4.0 / 1e6, 1), "unit": "M VALU instr/s per SIMD",
-                    "frac": round(4.0 * valu / cycles, 4), "critical_wave_valu": valu, "wave_cycles": cycles, "clock_ghz": round(clock / 1e9, 3),
-                    "source": "instruction and cycle counts: committed SQ counter pass (profiles/" + PMC_FILE.replace("pmc_traffic", "substeps_pmc")
-                              + "); durations: HIP events in this run"})
+        # VALU issue rate of the critical wave (a physics wave: it executes the most instructions and lives for the whole launch) against one
+        # instruction per 4 cycles of its SIMD.  The clock is the IN-KERNEL one, measured with s_memtime / s_memrealtime stamps in the section-
+        # timing build (profiles/*_substeps_clock.json): 2.36 GHz -- SQ_WAVE_CYCLES x 4 / duration, used until late in round 3, reads 1.63 GHz for
+        # the same launch and overstated the fraction (0.63 instead of 0.44).
+        valu = pmc["critical_wave_valu_per_lg_step"]
+        clock_ghz, clock_src = 2.4, "nominal 2.4 GHz (no committed in-kernel measurement found)"
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE.replace("pmc_traffic", "substeps_clock"))) as f:
+                clock_ghz = float(json.load(f)["clock_ghz_in_kernel"])
+            clock_src = "in-kernel clock: committed s_memtime / s_memrealtime stamps (profiles/" + PMC_FILE.replace("pmc_traffic", "substeps_clock") + ")"
+        except (OSError, ValueError, KeyError):
+            pass
+        cycles = clock_ghz * 1e9 * ms_loop * 1e-3
+        out.update({"achieved": round(valu / (ms_loop * 1e-3) / 1e6, 1), "peak": round(clock_ghz * 1e3 / 4.0, 1), "unit": "M VALU instr/s per SIMD",
+                    "frac": round(4.0 * valu / cycles, 4), "critical_wave_valu": valu, "launch_cycles": round(cycles), "clock_ghz": clock_ghz,
+                    "source": "instruction counts: committed SQ counter pass (profiles/" + PMC_FILE.replace("pmc_traffic", "substeps_pmc")
+                              + "); " + clock_src + "; duration: HIP events in this run"})
     return out
 
 

@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
 #ifdef LG_PROF_SUBSTEPS
     for (int k = 0; k < 16; ++k) pr.acc[k] = 0;
     pr.last = __builtin_amdgcn_s_memtime();
+    const unsigned long long prof_rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz: in-kernel clock = ticks / realtime x 0.1 GHz
 #endif
     __shared__ float s_ct[LG_NUM_SLOTS * LG_CT_NF * 64];
     __shared__ float s_lk[J * LG_LK_NF * 64];
@@ -298,6 +299,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
     }
 #ifdef LG_PROF_SUBSTEPS
     PSTAMP(pr, 14);
+    pr.acc[15] = __builtin_amdgcn_s_memrealtime() - prof_rt0;
     if ((tid & 63) == 0 && wave < 2 && blockIdx.x < 16)
         for (int k = 0; k < 16; ++k) P->dbg_cycles[(blockIdx.x * 2 + wave) * 16 + k] = pr.acc[k];
 #endif

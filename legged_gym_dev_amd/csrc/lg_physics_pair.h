@@ -1,8 +1,9 @@
 // Pair-lane articulated-body physics for gfx950: TWO lanes per (environment, leg).
 //
 // Same algorithm, same LDS records and same results (up to fp32 summation order) as physics_lane in lg_physics.h; the
-// difference is the lane map.  The control loop is bound by the VALU issue rate of the one wave per CU that runs the
-// physics (profiles/r02_substeps_pmc.json), and most of that work is 6-vector / 6x6 arithmetic.  Here the two lanes of a
+// difference is the lane map.  The control loop lasts as long as the dependent instruction chain of the wave that runs the
+// physics (it fills about half of its VALU issue slots: profiles/r03_substeps_pmc.json, r03_substeps_clock.json), and most of
+// that chain is 6-vector / 6x6 arithmetic.  Here the two lanes of a
 // pair split every spatial quantity by rows: lane h = 0 holds the angular half (w rows), lane h = 1 the linear half
 // (v rows) of every spatial vector, and the matching three rows of every 6x6 matrix, stored as two 3x3 blocks relative to
 // the lane's own role:  mm multiplies the lane's own half of an operand, mo the partner's half.  With that convention a

@@ -8,6 +8,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_gpu_tests
 python tools/env_step_time.py 2>&1 | grep -v "amdgpu.ids\|Setting seed" > gpurun_out/${TAG}_env_step_time.txt; cat gpurun_out/${TAG}_env_step_time.txt
 # phase clocks need the stamped build (make prof in legged_gym_dev_amd/csrc)
 LG_HIP_LIB=$GRAFT_REPO_ROOT/legged_gym_dev_amd/lib/liblegged_hip_prof.so python tools/post_step_phases.py 2>&1 | grep cycles > gpurun_out/${TAG}_post_step_phases.txt; cat gpurun_out/${TAG}_post_step_phases.txt
+LG_CLOCK_JSON=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_substeps_clock.json LG_HIP_LIB=$GRAFT_REPO_ROOT/legged_gym_dev_amd/lib/liblegged_hip_prof.so python tools/substeps_sections.py anymal_c_flat 2>&1 | grep -v "amdgpu.ids\|Setting seed" > gpurun_out/${TAG}_substeps_sections.txt; cat gpurun_out/${TAG}_substeps_sections.txt
 cd /tmp && export TMPDIR=/tmp
 B="--no_cpu_baseline --no_alt --no_other --sustained 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $B > /dev/null 2>&1

@@ -26,7 +26,16 @@ for task in (sys.argv[1:] or ["anymal_c_flat"]):
             env.core.lib.lg_debug_post_step_cycles(env.core.ctx, buf)
             tot += np.array(buf[:], dtype=np.float64).reshape(32, 16).mean(0)
     tot /= 20
-    print(f"{task}: {tot.sum():.0f} ticks per launch")
-    for n, v in zip(NAMES, tot):
-        print(f"  {n:10s} {v:9.0f}  {100 * v / tot.sum():5.1f}%")
+    ticks, real = tot[:15].sum(), tot[15]                 # s_memtime ticks of the sections; s_memrealtime (100 MHz) over the same span
+    print(f"{task}: {ticks:.0f} ticks per launch over {real / 100.0:.1f} us: in-kernel clock {ticks / real * 0.1:.2f} GHz")
+    for n, v in zip(NAMES, tot[:15]):
+        print(f"  {n:10s} {v:9.0f}  {100 * v / ticks:5.1f}%")
+    if os.environ.get("LG_CLOCK_JSON") and task == "anymal_c_flat":       # what bench.py's roofline_env_step prices the VALU issue rate with
+        import json
+        json.dump({"workload": "anymal_c_flat, 4096 envs, k_substeps physics waves of the first 16 workgroups (make prof build)",
+                   "critical_wave_ticks": round(float(ticks)), "critical_wave_us": round(float(real) / 100.0, 2),
+                   "clock_ghz_in_kernel": round(float(ticks / real * 0.1), 3),
+                   "sections_percent": {n: round(100 * float(v) / float(ticks), 1) for n, v in zip(NAMES, tot[:15])},
+                   "note": "s_memtime ticks between the kernel's first and last stamp over s_memrealtime (100 MHz) of the same span"},
+                  open(os.environ["LG_CLOCK_JSON"], "w"), indent=1)
     env.close()
