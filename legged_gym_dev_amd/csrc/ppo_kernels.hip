@@ -752,8 +752,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, int z, int M, i
     }
 }
 
+#ifdef LG_EXP_GEMM_CLOCK             // diagnostic build only (make exp): in-kernel clock of the GEMM workgroups, s_memtime / s_memrealtime
+__device__ unsigned long long g_gemm_clk[2 * 2048];
+extern "C" void ppok_debug_read_gemm_clock(unsigned long long *host) { (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_clk), sizeof(g_gemm_clk)); }
+#endif
 template <bool A_RC, bool B_RC, int EPI, int TM, int TN, bool DBUF, bool X6 = false, int WGM = 2, int WGN = 2, int B_PL = 0, bool LDB = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, X6 ? (WGM * WGN == 8 ? 4 : 2) : 1) k_gemm(GemmArgs g) {
+#ifdef LG_EXP_GEMM_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+    struct ClkEnd { unsigned long long t0, r0; __device__ ~ClkEnd() {
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.z;
+        if (threadIdx.x == 0 && b < 2048) { g_gemm_clk[2 * b] = __builtin_amdgcn_s_memtime() - t0; g_gemm_clk[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - r0; } } } clk_end{clk_t0, clk_r0};
+#endif
     static_assert(B_PL == 0 || (X6 && (B_PL == 1) == B_RC), "weight planes feed the split-bf16 mainloop: [n][k] planes as the reduction-"
                   "contiguous operand (1), the same planes read along their rows through the transposing LDS read (2)");
     constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;       // WGM x WGN waves, each TM x TN tiles of 32x32
