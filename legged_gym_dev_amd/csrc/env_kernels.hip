@@ -199,6 +199,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
     const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
     float *cf = s_cf + pe * B * 3;
+    const PhysCfg pk = phys_cfg(P);            // the physics' launch constants, in registers for the whole control loop
+    const float action_scale = c.action_scale;
     PSTAMP(pr, 0);
     for (int sub = 0; sub < iters; ++sub) {
         // ---- torques
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const int rl = r * RPP + (tid >> 3);
-                    x0[r] = (s_act[rl] * c.action_scale + c.default_dof_pos[rl % A] - s_q[rl]) * s_w[0];
+                    x0[r] = (s_act[rl] * action_scale + c.default_dof_pos[rl % A] - s_q[rl]) * s_w[0];
                     x1[r] = s_qd[rl] * s_w[1];
                 }
                 lstm8_rows<NR>(s_w + 4 + (tid & 7) * LG_LSTM_REC, tid & 7, x0, x1, h0, c0, h1, c1, y);
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     const int d = leg * J + j;
-                    const float as = s_act[live ? rl0 + j : 0] * c.action_scale;
+                    const float as = s_act[live ? rl0 + j : 0] * action_scale;
                     float t;
                     if (c.control_type == 0) t = c.p_gains[d] * (as + c.default_dof_pos[d] - q[j]) - c.d_gains[d] * qd[j];
                     else if (c.control_type == 1)
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
                 bool fault;
                 V3 fb;
                 if constexpr (PAIR) {
-                    fault = physics_pair<L, J>(P, leg, hrole, tid >> 1, tid, dt, root, q, qd, tau, fr, dm, s_mat + 4 * pe, fslot, fbase, s_ct, s_lk,
+                    fault = physics_pair<L, J>(pk, leg, hrole, tid >> 1, tid, dt, root, q, qd, tau, fr, dm, s_mat + 4 * pe, fslot, fbase, s_ct, s_lk,
                                                s_lk + J * LG_LKP_NF * 64, s_lt, s_lm, pr);
                     fb = pleg_sum<L>(fbase);
                 } else {
@@ -256,11 +258,11 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
                 if (last && live && writer) {
 #pragma unroll
                     for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k)
-                        if (k < P->n_leg_slots) {
+                        if (k < pk.n_leg_slots) {
                             float *o = cf + 3 * P->slot_body[k][leg];
                             o[0] += wgt * fslot[k].x; o[1] += wgt * fslot[k].y; o[2] += wgt * fslot[k].z;
                         }
-                    if (leg == 0 && P->n_base_spheres > 0) {
+                    if (leg == 0 && pk.n_base_spheres > 0) {
                         float *o = cf + 3 * P->base_body[0];
                         o[0] += wgt * fb.x; o[1] += wgt * fb.y; o[2] += wgt * fb.z;
                     }

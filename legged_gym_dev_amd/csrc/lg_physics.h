@@ -122,16 +122,47 @@ __device__ __forceinline__ Sv leg_sum(Sv a) {
     return {{leg_sum<L>(a.w.x), leg_sum<L>(a.w.y), leg_sum<L>(a.w.z)}, {leg_sum<L>(a.v.x), leg_sum<L>(a.v.y), leg_sum<L>(a.v.z)}};
 }
 
-struct Ground { float h; V3 n; };
-__device__ __forceinline__ Ground ground_at(const DevParams *P, float x, float y) {
+// The scalars of DevParams the physics reads in every substep, copied into registers ONCE per launch (phys_cfg): read through P they are
+// scalar loads the compiler must repeat after every workgroup barrier of the control loop (29 s_load per substep pass, each cluster a
+// ~150-cycle wait for the lone physics wave).  Field names follow lg_cfg, so the physics reads `c.<name>` either way.
+struct PhysCfg {
+    float gravity[3];
+    float max_depenetration_velocity, contact_erp, ground_restitution, ground_friction, contact_offset, bounce_threshold;
+    float border_size, hf_hscale, hf_vscale;
+    int hf_rows, hf_cols, terrain_type, solver_iterations, material_rand;
+    int n_leg_slots, n_base_spheres;
+    unsigned long long slot_link_pk;
+    const int16_t *height_samples;
+    float base_mass, base_com[3], base_inertia[9];
+};
+__device__ __forceinline__ PhysCfg phys_cfg(const DevParams *__restrict__ P) {
     const lg_cfg &c = P->cfg;
+    PhysCfg k;
+    for (int i = 0; i < 3; ++i) k.gravity[i] = c.gravity[i];
+    k.max_depenetration_velocity = c.max_depenetration_velocity; k.contact_erp = c.contact_erp;
+    k.ground_restitution = c.ground_restitution; k.ground_friction = c.ground_friction;
+    k.contact_offset = c.contact_offset; k.bounce_threshold = c.bounce_threshold;
+    k.border_size = c.border_size; k.hf_hscale = c.hf_hscale; k.hf_vscale = c.hf_vscale;
+    k.hf_rows = c.hf_rows; k.hf_cols = c.hf_cols; k.terrain_type = c.terrain_type;
+    k.solver_iterations = c.solver_iterations; k.material_rand = c.material_rand;
+    k.n_leg_slots = P->n_leg_slots; k.n_base_spheres = P->n_base_spheres; k.slot_link_pk = P->slot_link_pk;
+    k.height_samples = P->height_samples;
+    k.base_mass = P->model.mass[0];
+    for (int i = 0; i < 3; ++i) k.base_com[i] = P->model.com[0][i];
+    for (int i = 0; i < 9; ++i) k.base_inertia[i] = P->model.inertia[0][i];
+    return k;
+}
+
+struct Ground { float h; V3 n; };
+template <typename CFG>
+__device__ __forceinline__ Ground ground_at(const CFG &c, const int16_t *__restrict__ height_samples, float x, float y) {
     if (c.terrain_type == 0) return {0.0f, {0.0f, 0.0f, 1.0f}};
     float gx = (x + c.border_size) / c.hf_hscale, gy = (y + c.border_size) / c.hf_hscale;
     gx = fminf(fmaxf(gx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
     gy = fminf(fmaxf(gy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
     int ix = (int)gx, iy = (int)gy;
     float tx = gx - ix, ty = gy - iy;
-    const int16_t *hs = P->height_samples + (size_t)ix * c.hf_cols + iy;
+    const int16_t *hs = height_samples + (size_t)ix * c.hf_cols + iy;
     float h00 = (float)hs[0] * c.hf_vscale, h01 = (float)hs[1] * c.hf_vscale;
     float h10 = (float)hs[c.hf_cols] * c.hf_vscale, h11 = (float)hs[c.hf_cols + 1] * c.hf_vscale;
     float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
@@ -311,7 +342,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
                 rad = lt[LG_LT_SLOTS + 4 * s + 3];
             }
             V3 cw = xw + mul(Rb, cbk);
-            Ground g = ground_at(P, cw.x, cw.y);
+            Ground g = ground_at(P->cfg, P->height_samples, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
             if (c.material_rand) gap -= mat[2];                 // shape thickness: the robot rests that far off the surface
             if (gap < c.contact_offset) {

@@ -138,14 +138,12 @@ struct SubProf {};
 // of the pair and come back identical.  pcol = column of the pair (0..63) in the contact / limit / shared link records,
 // lcol = column of the lane (0..127) in the per-lane link records.
 template <int L, int J>
-__device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, int leg, bool h, int pcol, int lcol, float dt,
+__device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): registers */, int leg, bool h, int pcol, int lcol, float dt,
                                              float *root, float *q, float *qd, const float *tau, float friction, float dmass,
                                              const float *__restrict__ mat /* LDS: this env's restitution, compliance, thickness */,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkp,
                                              float *__restrict__ lkh, const float *__restrict__ ltab, float *__restrict__ lmt,
                                              SubProf &pr) {
-    const lg_cfg &c = P->cfg;
-    const lg_model &m = P->model;
     const float *__restrict__ lt = ltab + leg * LG_LT_STRIDE;
     const M3 Rb = quat_to_mat(root + 3);
     const V3 xw = {root[0], root[1], root[2]};
@@ -153,8 +151,8 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
     const V3 gb = mulT(Rb, V3{c.gravity[0], c.gravity[1], c.gravity[2]});
     const V3 vel0 = sel3(h, vb, wb), vel0o = sel3(h, wb, vb);
     const V3 zero3 = {0.f, 0.f, 0.f};
-    const int nslots = P->n_leg_slots;
-    const unsigned long long link_pk = P->slot_link_pk;      // sphere slot -> link, 4 bits per slot
+    const int nslots = c.n_leg_slots;
+    const unsigned long long link_pk = c.slot_link_pk;      // sphere slot -> link, 4 bits per slot
 
 #define LKP(j, f) lkp[((j) * LG_LKP_NF + (f)) * 64 + pcol]
 #define CF(si, f) cst[((si) * LG_CT_NF + (f)) * 64 + pcol]
@@ -243,7 +241,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
     }
     PSTAMP(pr, 3);
     // floating base
-    H6 I0 = rigid_inertia_h(h, m.mass[0] + dmass, ld3(m.com[0]), load3(m.inertia[0]));
+    H6 I0 = rigid_inertia_h(h, c.base_mass + dmass, ld3(c.base_com), load3(c.base_inertia));
     const V3 I0v = hmul(I0, vel0, vel0o);
     const V3 pA0 = crf_h(h, vel0, vel0o, I0v, px3(I0v)) + pleg_sum<L>(pa_run);
 #pragma unroll
@@ -282,12 +280,12 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
     // values to the same column (each lane reads back what it wrote itself; no cross-lane ordering is relied on).
     const float mu = 0.5f * (friction + c.ground_friction);
     unsigned amask = 0u;
-    const int nbase_it = (P->n_base_spheres + L - 1) / L;
+    const int nbase_it = (c.n_base_spheres + L - 1) / L;
     for (int s = 0; s < nslots + nbase_it; ++s) {
         const bool is_base = s >= nslots;
         const int ub = s - nslots;
         const int si = is_base ? LG_MAX_LEG_SLOTS + ub : s;
-        const bool exists = is_base ? (leg + ub * L < P->n_base_spheres) : true;
+        const bool exists = is_base ? (leg + ub * L < c.n_base_spheres) : true;
         V3 cbk = {0.f, 0.f, 0.f}, Pc = {0.f, 0.f, 0.f}, nb = {0.f, 0.f, 1.f};
         float rad = 0.f, vtarget = 0.f;
         bool active = false;
@@ -300,7 +298,7 @@ __device__ __forceinline__ bool physics_pair(const DevParams *__restrict__ P, in
                 rad = lt[LG_LT_SLOTS + 4 * s + 3];
             }
             V3 cw = xw + mul(Rb, cbk);
-            Ground g = ground_at(P, cw.x, cw.y);
+            Ground g = ground_at(c, c.height_samples, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
             if (c.material_rand) gap -= mat[2];                 // shape thickness: the robot rests that far off the surface
             if (gap < c.contact_offset) {
