@@ -448,6 +448,12 @@ def main():
                       "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
     out["config"]["physics_fault_resets"] = faults
+    if world > 1:
+        # the GEMM-group probe on every rank (a communicator that reduces inside the backward pass needs all of them in it); rank 0 reports
+        rf = gemm_roofline(runner, hidden, with_largest=False, task=args.task)
+        if rank == 0:
+            rf["traffic_source"] = "committed single-GPU PMC passes (profiles/" + PMC_FILE + "); not collected during this run"
+            out["roofline"] = rf
     if rank == 0 and world == 1:
         out["roofline"] = gemm_roofline(runner, hidden, task=args.task)
         out["roofline"]["traffic_source"] = ("committed PMC passes of this command (profiles/" + PMC_FILE + ": rocprofv3 --pmc FETCH_SIZE / "

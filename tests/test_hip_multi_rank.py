@@ -204,6 +204,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"]["bound"] == "mfma" and 0.0 < out["roofline"]["frac"] < 1.0     # the GEMM-group probe also runs with N > 1
     assert out["config"]["num_envs_per_gpu"] == 256
     # a rank that dies takes the job down with a non-zero code
     env["LG_BENCH_FAIL_RANK"] = "1"
