@@ -63,11 +63,44 @@ def make_runner(num_envs, hidden, device, rank, world, task="anymal_c_flat"):
     return env, runner
 
 
-def time_iterations(runner, steps, warmup, world):
+class TimedReduce:
+    """HIP events around every all-reduce the update issues between backward and optimiser step (TorchDistComm: the collective is
+    serial on the learner's stream, so event-to-event time IS the communication time of the minibatch)."""
+
+    def __init__(self, fn):
+        self.fn, self.pairs = fn, []
+
+    def __call__(self, t):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.fn(t)
+        e1.record()
+        self.pairs.append((e0, e1))
+
+    def total_ms(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        n, self.pairs = len(self.pairs), []
+        return ms, n
+
+
+def time_iterations(runner, steps, warmup, world, comm_out=None):
+    """(wall seconds of the `steps` timed iterations = MAX over ranks, rollout seconds of as many iterations).  With world > 1 and
+    `comm_out` a dict: per-rank communication time of the timed iterations (ms per iteration on every rank: the all-reduces of the
+    default collective, or what the learner's stream waited for the overlapped buckets of LG_COMM=native) and every rank's own
+    iteration time, so that a scaling loss can be attributed."""
     ar = runner._grad_reduce
     for _ in range(warmup):
         runner.rollout()
         runner.ppo.update(ar)
+    timed = None
+    native = world > 1 and getattr(runner.comm, "overlapped", False)
+    if world > 1 and comm_out is not None:
+        if native:
+            runner.ppo.comm_wait_ms()                # clear
+            runner.ppo.comm_timing(True)
+        elif ar is not None:
+            timed = ar = TimedReduce(ar)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -76,10 +109,29 @@ def time_iterations(runner, steps, warmup, world):
         runner.rollout()
         runner.ppo.update(ar)
     torch.cuda.synchronize()
+    el_own = time.perf_counter() - t0            # this rank's own time, before it waits for the others
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if world > 1 and comm_out is not None:
+        if native:
+            ms, n = runner.ppo.comm_wait_ms()
+            runner.ppo.comm_timing(False)
+        else:
+            ms, n = timed.total_ms() if timed is not None else (0.0, 0)
+        ar = runner._grad_reduce
+        mine = torch.tensor([ms / steps, 1e3 * el_own / steps, float(n) / steps], device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        comm_out.update({"backend": "native (RCCL through lg_comm_*, per-layer buckets inside the backward pass; ms = the learner stream's wait "
+                                    "for the last bucket)" if native else
+                                    f"torch.distributed {torch.distributed.get_backend()} (one all-reduce of [gradients | KL] per optimiser step; "
+                                    "ms = HIP events around the collective)",
+                         "comm_ms_per_step_by_rank": [round(float(v[0]), 4) for v in allr],
+                         "iter_ms_by_rank": [round(float(v[1]), 3) for v in allr],
+                         "collectives_per_step": round(float(allr[0][2]), 1),
+                         "iter_ms_min": round(min(float(v[1]) for v in allr), 3), "iter_ms_max": round(max(float(v[1]) for v in allr), 3)})
     # informative rollout/update split, measured separately with a sync between the phases
     t_roll = 0.0
     for _ in range(2):
@@ -295,7 +347,7 @@ def lg_step_us(env, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-def other_config(task, num_envs, hidden, device, steps=6, warmup=3):
+def other_config(task, num_envs, hidden, device, steps=6, warmup=3, sustained=0):
     """BASELINE.json configs[2] / configs[4] beside the bench line: the same whole-iteration measurement on another task."""
     env, runner = make_runner(num_envs, hidden, device, 0, 1, task=task)
     try:
@@ -313,11 +365,42 @@ def other_config(task, num_envs, hidden, device, steps=6, warmup=3):
                "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_minibatch", "flops_per_minibatch")},
                "us_per_lg_step": round(lg_step_us(env), 2),
                "resets_per_env_step": round(ep_done / max(runner.num_steps_per_env * num_envs * (iters - 1), 1), 5),
-               "physics_fault_resets": int(env.fault_total.cpu())}
+               "physics_fault_resets": int(env.fault_total.cpu()), "base_velocity_clamps": int(env.vel_clamp_total.cpu())}
+        if sustained > 0:
+            out["sustained"] = sustained_pass(env, runner, hidden, sustained, runner.num_steps_per_env * num_envs, ep_done, task)
         return out
     finally:
         env.close()
         runner.ppo.close()
+
+
+def sustained_pass(env, runner, hidden, iters, steps_per_iter, ep_done, task):
+    """`iters` more iterations of the same loop with no host synchronisation inside: the timed K steps are a burst of a few hundred
+    ms, a training run settles at the power / thermal state of minutes of load.  Two probes separate the chip's state from the
+    workload's drift: the largest GEMM of the update on FIXED synthetic operands before and after the pass (same data, same launch:
+    its change is clocks alone), and the GEMM group of a real update on the storage the pass leaves behind."""
+    R = runner.ppo.T * runner.ppo.N // runner.ppo.cfg.num_mini_batches
+    faults0, clamps0 = int(env.fault_total.cpu()), int(env.vel_clamp_total.cpu())
+    fixed0 = single_gemm_roofline(R, hidden)["us"]
+    ar = runner._grad_reduce
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        runner.rollout()
+        runner.ppo.update(ar)
+    torch.cuda.synchronize()
+    s_el = time.perf_counter() - t0
+    fixed1 = single_gemm_roofline(R, hidden)["us"]
+    ep2 = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
+    return {"iterations": iters, "value": round(steps_per_iter * iters / s_el, 1), "unit": "env-steps/s",
+            "ms_per_step": round(1e3 * s_el / iters, 3), "seconds": round(s_el, 2),
+            "resets_per_env_step": round((ep2 - ep_done) / (steps_per_iter * iters), 5),
+            "physics_fault_resets": int(env.fault_total.cpu()) - faults0,
+            "base_velocity_clamps": int(env.vel_clamp_total.cpu()) - clamps0,
+            "policy_std_at_end": round(float(runner.ppo.param_views["std"].mean()), 3),
+            "gemm_fixed_operands_us_before": fixed0, "gemm_fixed_operands_us_after": fixed1,
+            "power_state_slowdown": round(fixed1 / fixed0, 4),
+            "gemm_ms_per_minibatch_at_end": gemm_roofline(runner, hidden, with_largest=False, task=task)["ms_per_minibatch"]}
 
 
 def rank_environments(n, port, base=None, comm_port=None):
@@ -426,7 +509,8 @@ def main():
     if args.task != "anymal_c_flat":
         env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
         args.no_other = args.no_alt = args.no_cpu_baseline = True
-    el, t_roll = time_iterations(runner, args.steps, args.warmup, world)
+    comm_info = {} if world > 1 else None
+    el, t_roll = time_iterations(runner, args.steps, args.warmup, world, comm_out=comm_info)
     steps_per_iter = runner.num_steps_per_env * args.num_envs * world
     sustained = None
     # what the timed steps were measured on: how often the random-init policy makes robots fall, and how often the
@@ -443,11 +527,15 @@ def main():
            "config": {"workload": f"{args.task}, {args.num_envs} envs/GPU, 24 env steps/iter (decimation 4, "
                                   f"{'actuator LSTM' if env.setup.use_actuator_net else 'PD law'}, "
                                   f"ABA+contact), PPO 5 epochs x 4 minibatches, ActorCritic {hidden}",
-                      "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden, "parallelism": f"env-shard x{world}",
+                      "num_envs_per_gpu": args.num_envs, "policy_hidden": hidden,
+                      "parallelism": f"env-shard x{world}" + (f", LG_COMM={os.environ.get('LG_COMM', 'torch')}" if world > 1 else ""),
                       "rollout_ms": round(1e3 * t_roll / args.steps, 3),
                       "update_ms": round(1e3 * (el - t_roll) / args.steps, 3)}}
     out["config"]["resets_per_env_step"] = round(ep_done / max(steps_done, 1), 5)
     out["config"]["physics_fault_resets"] = faults
+    out["config"]["base_velocity_clamps"] = int(env.vel_clamp_total.cpu())
+    if comm_info:
+        out["comm"] = comm_info
     if world > 1:
         # the GEMM-group probe on every rank (a communicator that reduces inside the backward pass needs all of them in it); rank 0 reports
         rf = gemm_roofline(runner, hidden, with_largest=False, task=args.task)
@@ -460,34 +548,18 @@ def main():
                                              "WRITE_SIZE in separate runs); not collected during this run")
         out["roofline_env_step"] = env_roofline(env) if args.task == "anymal_c_flat" else {"us_per_lg_step": round(lg_step_us(env), 2)}
         if args.sustained > 0:   # after the probes above: they are taken in the state the timed steps ran in
-            # the timed K steps are a burst of a few hundred ms; a training run settles at the power / thermal state of minutes
-            # of load.  Same loop, `sustained` iterations, no host synchronisation inside.
-            ar = runner._grad_reduce
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.sustained):
-                runner.rollout()
-                runner.ppo.update(ar)
-            torch.cuda.synchronize()
-            s_el = time.perf_counter() - t0
-            ep2 = int(runner.ppo.t["ep_ring_count"].cpu()) & 0xFFFFFFFF
-            sustained = {"iterations": args.sustained, "value": round(steps_per_iter * args.sustained / s_el, 1), "unit": "env-steps/s",
-                         "ms_per_step": round(1e3 * s_el / args.sustained, 3), "seconds": round(s_el, 2),
-                         "resets_per_env_step": round((ep2 - ep_done) / (steps_per_iter * args.sustained), 5),
-                         "physics_fault_resets": int(env.fault_total.cpu()) - faults,
-                         "policy_std_at_end": round(float(runner.ppo.param_views["std"].mean()), 3),
-                         "note": "the fork's anymal_c_flat reward is identically 0 after its positive clip (commands x, y = 0: SURVEY.md 0.8), so over "
+            sustained = sustained_pass(env, runner, hidden, args.sustained, steps_per_iter, ep_done, args.task)
+            sustained["note"] = ("the fork's anymal_c_flat reward is identically 0 after its positive clip (commands x, y = 0: SURVEY.md 0.8), so over "
                                  "hundreds of iterations PPO's entropy bonus alone inflates the policy's std and its actions (|a| up to the clip of "
-                                 "100): robots thrash, resets per env-step rise 3x and a few envs per million steps exceed the physics guard's "
-                                 "141 rad/s (tools/diag_faults.py, profiles/r03_diag_faults.txt).  Workload drift and power state both enter this figure"}
-        if sustained:
-            # the same GEMM-group probe in the state the sustained pass leaves the chip in (power / clocks), beside the burst-state one
-            sustained["gemm_ms_per_minibatch_at_end"] = gemm_roofline(runner, hidden, with_largest=False, task=args.task)["ms_per_minibatch"]
+                                 "100): robots thrash and resets per env-step rise.  power_state_slowdown (one GEMM launch on fixed synthetic operands "
+                                 "before / after the pass) is the chip's clocks alone; what remains of the gap to the burst figure is that drift of "
+                                 "the workload.  other_configs[anymal_c_rough].sustained is the same pass on a task whose reward has a signal")
             out["sustained"] = sustained
         env.close()
         runner.ppo.close()
         if not args.no_other:
-            out["other_configs"] = [other_config(t, args.num_envs, hidden, device) for t in ("anymal_c_rough", "cassie")]
+            out["other_configs"] = [other_config(t, args.num_envs, hidden, device, sustained=(args.sustained // 2 if t == "anymal_c_rough" else 0))
+                                    for t in ("anymal_c_rough", "cassie")]
         if tuple(hidden) != (128, 64, 32) and not args.no_alt:
             env2, runner2 = make_runner(args.num_envs, [128, 64, 32], device, rank, world)
             el2, tr2 = time_iterations(runner2, max(3, args.steps // 2), 2, world)

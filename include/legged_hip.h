@@ -183,6 +183,12 @@ typedef struct lg_cfg {
     float gravity[3], ground_friction;    /* ground mu; combined with the env's mu by averaging */
     float contact_offset, max_depenetration_velocity, contact_erp;
     float bounce_threshold;               /* sim.physx.bounce_threshold_velocity: approach speeds below it do not bounce */
+    /* asset options the simulator is given (legged_robot.py:692-705): */
+    float max_linear_velocity, max_angular_velocity;   /* :701-702: the base's velocities are clamped at these magnitudes after every
+                                                          solve, as PhysX clamps a body's (0 = no clamp); each clamp is counted */
+    float armature;                       /* :703: added to the inertia every joint sees about its own axis */
+    float rest_offset;                    /* :704 thickness: the robot's shapes come to rest this far off a surface; replaced per env by
+                                             lg_buffers.material[.][2] when that property is randomised (material_rand) */
     int32_t num_xterms, feet_air_time_ungated /* trajectory env: no command gate (legged_robot_trajectory.py:1071-1080) */;
     int32_t num_terms, _pad4;
     int32_t term_order[LG_NUM_TERMS];   /* active terms (builtin id, or LG_NUM_REWARDS + xterm index) in the order the
@@ -220,8 +226,11 @@ typedef struct lg_buffers {
                                              and the number of steps summed -- rsl_rl's log() averages infos["episode"] over every
                                              step of an iteration; the reader divides and clears */
     int32_t *n_reset;                     /* 1: envs reset by the last step */
-    int32_t *n_fault;                     /* 1: envs the physics fault guard stopped during the last step (they are among n_reset) */
+    int32_t *n_fault;                     /* 1: envs whose solve came back non-finite during the last step: brought to rest and reset (they are among n_reset) */
     int64_t *fault_total;                 /* 1: the same, summed since lg_create */
+    int32_t *n_vel_clamp;                 /* 1: physics substeps of the last step in which an env's base velocity was clamped at
+                                             max_linear_velocity / max_angular_velocity (the env carries on, as under PhysX) */
+    int64_t *vel_clamp_total;             /* 1: the same, summed since lg_create */
     /* trajectory env (all unused otherwise): */
     float *tg_state;                      /* (N, LG_TG_STRIDE) generator state, LG_TG_* */
     float *tg_traj;                       /* (N, traj.N * traj.dN + 1, 2) ROM states, oldest first */
@@ -387,6 +396,11 @@ int lg_comm_broadcast(lg_comm *c, float *buf, int64_t n, int root, void *stream)
 int lg_ppo_set_comm(lg_ppo *p, lg_comm *c);
 int lg_ppo_allreduce_adv_moments(lg_ppo *p, lg_comm *c);   /* between lg_ppo_compute_returns and lg_ppo_normalize_advantages */
 int lg_ppo_broadcast_params(lg_ppo *p, lg_comm *c, int root);   /* identical initial policy on every rank */
+/* How long the learner's stream stood waiting for the gradient buckets (what the overlap did NOT hide), measured with HIP events
+ * around the wait of every minibatch while timing is enabled (at most 4096 minibatches are recorded, then recording stops).
+ * lg_ppo_comm_wait_ms synchronises the learner's stream, returns the sum in ms and the number of minibatches summed, and clears. */
+int lg_ppo_comm_timing(lg_ppo *p, int enable);
+int lg_ppo_comm_wait_ms(lg_ppo *p, double *ms_total, int64_t *minibatches);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ class lg_cfg(C.Structure):
         ("dof_pos_limits", f32 * 2 * MAX_DOF), ("dof_vel_limits", f32 * MAX_DOF), ("torque_limits", f32 * MAX_DOF),
         ("gravity", f32 * 3), ("ground_friction", f32),
         ("contact_offset", f32), ("max_depenetration_velocity", f32), ("contact_erp", f32), ("bounce_threshold", f32),
+        ("max_linear_velocity", f32), ("max_angular_velocity", f32), ("armature", f32), ("rest_offset", f32),
         ("num_xterms", i32), ("feet_air_time_ungated", i32), ("num_terms", i32), ("_pad4", i32),
         ("term_order", i32 * NUM_TERMS), ("xterms", lg_xterm * MAX_XTERMS), ("traj", lg_traj_cfg),
         ("lstm_w", f32 * LSTM_NW),
@@ -113,6 +114,7 @@ _BUF_FIELDS = [
     ("terrain_levels", PI64), ("terrain_types", PI64), ("lstm_h", PF), ("lstm_c", PF),
     ("friction", PF), ("base_mass_delta", PF), ("extras_episode", PF), ("extras_terrain_level", PF),
     ("extras_time_outs", PU8), ("extras_episode_acc", PF), ("n_reset", PI32), ("n_fault", PI32), ("fault_total", PI64),
+    ("n_vel_clamp", PI32), ("vel_clamp_total", PI64),
     ("tg_state", PF), ("tg_traj", PF), ("trajectory", PF), ("prev_error", PF), ("push_timer", PF),
     ("inject_uniforms", PF), ("inject_levels", PI64), ("material", PF)]
 
@@ -147,7 +149,7 @@ def buffer_shapes(N, A, B, O, F, H, traj_N=0, traj_dN=1):
         "base_mass_delta": ((N,), "f4"), "extras_episode": ((NUM_TERMS,), "f4"),
         "extras_terrain_level": ((1,), "f4"), "extras_time_outs": ((N,), "u1"),
         "extras_episode_acc": ((NUM_TERMS + 2,), "f4"), "n_reset": ((1,), "i4"),
-        "n_fault": ((1,), "i4"), "fault_total": ((1,), "i8"),
+        "n_fault": ((1,), "i4"), "fault_total": ((1,), "i8"), "n_vel_clamp": ((1,), "i4"), "vel_clamp_total": ((1,), "i8"),
         "inject_uniforms": ((N, K), "f4"), "inject_levels": ((N,), "i8"), "material": ((N, 4), "f4")}
 
 

@@ -186,7 +186,7 @@ int lg_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_sa
     DA(b.lstm_h, (size_t)2 * N * A * 8); DA(b.lstm_c, (size_t)2 * N * A * 8);
     DA(b.friction, N); DA(b.base_mass_delta, N);
     DA(b.extras_episode, LG_NUM_TERMS); DA(b.extras_terrain_level, 1); DA(b.extras_time_outs, N); DA(b.n_reset, 1);
-    DA(b.n_fault, 1); DA(b.fault_total, 1); DA(h.fault_count, 1); DA(b.extras_episode_acc, LG_NUM_TERMS + 2);
+    DA(b.n_fault, 1); DA(b.fault_total, 1); DA(h.fault_count, 1); DA(b.n_vel_clamp, 1); DA(b.vel_clamp_total, 1); DA(h.clamp_count, 1); DA(b.extras_episode_acc, LG_NUM_TERMS + 2);
     {
         const int npts = cfg->traj.enabled ? cfg->traj.N * cfg->traj.dN + 1 : 1, nobs = cfg->traj.enabled ? cfg->traj.N : 1;
         DA(b.tg_state, (size_t)N * LG_TG_STRIDE); DA(b.tg_traj, (size_t)N * npts * 2); DA(b.trajectory, (size_t)N * nobs * 2);

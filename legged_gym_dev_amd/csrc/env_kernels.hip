@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
             const bool last = sub == iters - 1;
             for (int s = 0; s < ns; ++s) {
                 V3 fslot[LG_MAX_LEG_SLOTS], fbase;
-                bool fault;
+                int fault;                                          // bit 0: non-finite solve (reset), bit 1: base velocity clamped
                 V3 fb;
                 if constexpr (PAIR) {
                     fault = physics_pair<L, J>(pk, leg, hrole, tid >> 1, tid, dt, root, q, qd, tau, fr, dm, s_mat + 4 * pe, fslot, fbase, s_ct, s_lk,
@@ -254,7 +254,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
                     fault = physics_lane<L, J>(P, leg, dt, root, q, qd, tau, fr, dm, s_mat + 4 * pe, fslot, fbase, s_ct, s_lk, s_lt, s_lm);
                     fb = {leg_sum<L>(fbase.x), leg_sum<L>(fbase.y), leg_sum<L>(fbase.z)};
                 }
-                if (fault && live && leg == 0 && writer) P->fault[env] = 1;
+                if ((fault & 1) && live && leg == 0 && writer) P->fault[env] = 1;
+                if ((fault & 2) && live && leg == 0 && writer) atomicAdd(P->clamp_count, 1);
                 if (last && live && writer) {
 #pragma unroll
                     for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k)

@@ -64,6 +64,7 @@ struct DevParams {
     int32_t *reset_count;          // 1
     int32_t *fault_count;          // 1: faults consumed by the running step (block atomics), folded by k_finalize
     uint8_t *fault;                // N: set by the physics fault guard, consumed by the post-step
+    int32_t *clamp_count;          // 1: base-velocity clamps (lg_cfg.max_linear_velocity / max_angular_velocity) since the last k_finalize
     uint8_t *reset_mark;           // N: envs reset since the last k_finalize (which clears it)
     int64_t *any_reset_step;       // 1: step counter of the last step on which at least one env reset (written by every post-step
                                    // workgroup that resets one; read by the fused rollout epilogue, ppo_mlp_fused.hip)

@@ -53,6 +53,8 @@ __device__ __forceinline__ void finalize_body(const DevParams *__restrict__ P, i
         P->buf.n_reset[0] = n; *P->reset_count = 0;
         const int nf = *P->fault_count;
         P->buf.n_fault[0] = nf; P->buf.fault_total[0] += nf; *P->fault_count = 0;
+        const int nc = *P->clamp_count;
+        P->buf.n_vel_clamp[0] = nc; P->buf.vel_clamp_total[0] += nc; *P->clamp_count = 0;
     }
     if (tid < LG_NUM_TERMS) P->ep_accum[tid] = 0.0f;
 }

@@ -128,6 +128,7 @@ __device__ __forceinline__ Sv leg_sum(Sv a) {
 struct PhysCfg {
     float gravity[3];
     float max_depenetration_velocity, contact_erp, ground_restitution, ground_friction, contact_offset, bounce_threshold;
+    float max_linear_velocity, max_angular_velocity, armature, rest_offset;
     float border_size, hf_hscale, hf_vscale;
     int hf_rows, hf_cols, terrain_type, solver_iterations, material_rand;
     int n_leg_slots, n_base_spheres;
@@ -142,6 +143,8 @@ __device__ __forceinline__ PhysCfg phys_cfg(const DevParams *__restrict__ P) {
     k.max_depenetration_velocity = c.max_depenetration_velocity; k.contact_erp = c.contact_erp;
     k.ground_restitution = c.ground_restitution; k.ground_friction = c.ground_friction;
     k.contact_offset = c.contact_offset; k.bounce_threshold = c.bounce_threshold;
+    k.max_linear_velocity = c.max_linear_velocity; k.max_angular_velocity = c.max_angular_velocity;
+    k.armature = c.armature; k.rest_offset = c.rest_offset;
     k.border_size = c.border_size; k.hf_hscale = c.hf_hscale; k.hf_vscale = c.hf_vscale;
     k.hf_rows = c.hf_rows; k.hf_cols = c.hf_cols; k.terrain_type = c.terrain_type;
     k.solver_iterations = c.solver_iterations; k.material_rand = c.material_rand;
@@ -187,7 +190,7 @@ __device__ __forceinline__ void tangents(V3 n, V3 &t1, V3 &t2) {
 //   root[13] (world: pos, quat xyzw, lin vel, ang vel), q[J], qd[J] of this leg's joints.
 // fslot[s] / fbase receive the world-frame contact force (N) of this lane's sphere slots.
 template <int L, int J>
-__device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
+__device__ __forceinline__ int physics_lane(const DevParams *__restrict__ P, int leg, float dt, float *root, float *q,
                                              float *qd, const float *tau, float friction, float dmass,
                                              const float *__restrict__ mat /* LDS: this env's restitution, compliance, thickness */,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkt,
@@ -259,7 +262,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             for (int b = 0; b < 6; ++b) IA.m[a][b] += Ia_run.m[a][b];
         pA = pA + pa_run;
         U[j] = mul6(IA, S[j]);
-        const float Dj = sdot(S[j], U[j]);
+        const float Dj = sdot(S[j], U[j]) + c.armature;
         u[j] = (tau[j] - jt[28] * qd[j]) - sdot(S[j], pA);
         float Uv[6] = {U[j].w.x, U[j].w.y, U[j].w.z, U[j].v.x, U[j].v.y, U[j].v.z};
         const float invD = frcp(Dj);
@@ -344,7 +347,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
             V3 cw = xw + mul(Rb, cbk);
             Ground g = ground_at(P->cfg, P->height_samples, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
-            if (c.material_rand) gap -= mat[2];                 // shape thickness: the robot rests that far off the surface
+            gap -= c.material_rand ? mat[2] : c.rest_offset;    // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
             if (gap < c.contact_offset) {
                 active = true;
                 nb = mulT(Rb, g.n);
@@ -412,12 +415,20 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     unsigned lmask = 0u;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31], vlim = lt[LG_LT_JOINT * j + 29];
         float sgn = 0.f, gap = 0.f;
         if (hi > lo) {
             const float qn = q[j] + dt * qdf[j];
             if (qn > hi) { sgn = 1.0f; gap = hi - q[j]; }
             else if (qn < lo) { sgn = -1.0f; gap = q[j] - lo; }
+        }
+        // the joint velocity limit rides in the same row (see lg_physics_pair.h): a joint-space impulse conserves momentum
+        float vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+        if (vlim > 0.0f) {
+            if (sgn == 0.f) {
+                if (qdf[j] > vlim) { sgn = 1.0f; vtarget = -vlim; }
+                else if (qdf[j] < -vlim) { sgn = -1.0f; vtarget = -vlim; }
+            } else vtarget = fmaxf(vtarget, -vlim);
         }
         const bool act = sgn != 0.f;
         if (!__any(act)) continue;                                   // wave-uniform: the usual case
@@ -443,7 +454,7 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
         if (act) {
             lmask |= 1u << j;
             LM(j, 0) = sgn;
-            LM(j, 1) = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+            LM(j, 1) = vtarget;
             LM(j, 2) = Wj > 1e-9f ? frcp(Wj) : 0.f;
             LM(j, 3) = 0.f;
         }
@@ -539,20 +550,21 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
 #undef CF
 #undef LK
 #undef LM
-    // ---- fault guard (PhysX never hands back non-finite or absurd state; neither may we): an env whose
-    // solve produced NaN/Inf or a base twist beyond 100 m/s | rad/s keeps its pose, is brought to rest and
-    // is reported so that the post-step terminates and resets it.
+    // ---- what PhysX does with a runaway body (asset options max_linear_velocity / max_angular_velocity, legged_robot.py:701-702):
+    // it clamps the velocity and carries on.  The guard is for non-finite state only (PhysX never hands back NaN / Inf; neither
+    // may we): such an env keeps its pose, is brought to rest and is reported so that the post-step terminates and resets it.
     float chk = dot(velf0.w, velf0.w) + dot(velf0.v, velf0.v);
 #pragma unroll
     for (int j = 0; j < J; ++j) chk += qdf[j] * qdf[j] * 1e-4f;
     chk = leg_sum<L>(chk);
-    if (!ok || !(chk < 2.0e4f)) {
+    if (!ok || !(chk < 3.0e38f)) {
 #pragma unroll
         for (int j = 0; j < J; ++j) qd[j] = 0.f;
 #pragma unroll
         for (int k = 7; k < 13; ++k) root[k] = 0.f;
-        return true;
+        return 1;
     }
+    int code = 0;
     // ---- integrate
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -571,6 +583,11 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     }
     V3 wn = velf0.w;
     V3 vn = velf0.v + dt * cross(wb, vb);
+    {   // the base's velocities as they are published, clamped at the asset's maxima
+        const float w2 = dot(wn, wn), v2 = dot(vn, vn);
+        if (c.max_angular_velocity > 0.0f && w2 > c.max_angular_velocity * c.max_angular_velocity) { wn = (c.max_angular_velocity * rsqrtf(w2)) * wn; code = 2; }
+        if (c.max_linear_velocity > 0.0f && v2 > c.max_linear_velocity * c.max_linear_velocity) { vn = (c.max_linear_velocity * rsqrtf(v2)) * vn; code = 2; }
+    }
     V3 vw = mul(Rb, vn), ww = mul(Rb, wn);
     root[0] += dt * vw.x; root[1] += dt * vw.y; root[2] += dt * vw.z;
     root[7] = vw.x; root[8] = vw.y; root[9] = vw.z;
@@ -588,5 +605,5 @@ __device__ __forceinline__ bool physics_lane(const DevParams *__restrict__ P, in
     float nrm = rsqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) qq[k] = qn[k] * nrm;
-    return false;
+    return code;
 }

@@ -138,7 +138,7 @@ struct SubProf {};
 // of the pair and come back identical.  pcol = column of the pair (0..63) in the contact / limit / shared link records,
 // lcol = column of the lane (0..127) in the per-lane link records.
 template <int L, int J>
-__device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): registers */, int leg, bool h, int pcol, int lcol, float dt,
+__device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): registers */, int leg, bool h, int pcol, int lcol, float dt,
                                              float *root, float *q, float *qd, const float *tau, float friction, float dmass,
                                              const float *__restrict__ mat /* LDS: this env's restitution, compliance, thickness */,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkp,
@@ -222,7 +222,7 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
             for (int b = 0; b < 3; ++b) { IA.mm.m[a][b] += Ia_run.mm.m[a][b]; IA.mo.m[a][b] += Ia_run.mo.m[a][b]; }
         pA = pA + pa_run;
         U[j] = hmul(IA, S[j]);
-        const float Dj = pdot(S[j], U[j]);
+        const float Dj = pdot(S[j], U[j]) + c.armature;
         u[j] = (tau[j] - jt[28] * qd[j]) - pdot(S[j], pA);
         const float invD = frcp(Dj);
         iD[j] = invD;
@@ -300,7 +300,7 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
             V3 cw = xw + mul(Rb, cbk);
             Ground g = ground_at(c, c.height_samples, cw.x, cw.y);
             float gap = (cw.z - g.h) * g.n.z - rad;
-            if (c.material_rand) gap -= mat[2];                 // shape thickness: the robot rests that far off the surface
+            gap -= c.material_rand ? mat[2] : c.rest_offset;    // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
             if (gap < c.contact_offset) {
                 active = true;
                 nb = mulT(Rb, g.n);
@@ -362,17 +362,29 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
     const float rl = frcp((float)max(n_leg_active, 1)), rb = frcp((float)max(n_base_active, 1));
 
     PSTAMP(pr, 7);
-    // ---- joint position limits
+    // ---- joint position limits, and the joint velocity limit as the same kind of row (a bound on the joint rate enforced by a JOINT-SPACE
+    // impulse, i.e. equal and opposite on child and parent: momentum is conserved).  Until round 4 the velocity limit was only the clamp
+    // at integration, which takes the child's excess rate away but leaves the base the reaction it was given for it -- a saturated
+    // joint pushed by a large torque then pumps angular momentum into the base substep after substep (profiles/r04_diag_faults.txt:
+    // base spins of hundreds of rad/s under actions of +-20 and more, what round 3's fault guard was resetting).
 #define LM(j, f) lmt[((j) * 4 + (f)) * 64 + pcol]
     unsigned lmask = 0u;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31], vlim = lt[LG_LT_JOINT * j + 29];
         float sgn = 0.f, gap = 0.f;
         if (hi > lo) {
             const float qn = q[j] + dt * qdf[j];
             if (qn > hi) { sgn = 1.0f; gap = hi - q[j]; }
             else if (qn < lo) { sgn = -1.0f; gap = q[j] - lo; }
+        }
+        // the outward rate the row allows: stop exactly at the position limit (or come back from beyond it), and never above the velocity limit
+        float vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+        if (vlim > 0.0f) {
+            if (sgn == 0.f) {
+                if (qdf[j] > vlim) { sgn = 1.0f; vtarget = -vlim; }
+                else if (qdf[j] < -vlim) { sgn = -1.0f; vtarget = -vlim; }
+            } else vtarget = fmaxf(vtarget, -vlim);
         }
         const bool act = sgn != 0.f;
         if (!__any(act)) continue;
@@ -398,7 +410,7 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
         if (act) {
             lmask |= 1u << j;
             LM(j, 0) = sgn;
-            LM(j, 1) = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+            LM(j, 1) = vtarget;
             LM(j, 2) = Wj > 1e-9f ? frcp(Wj) : 0.f;
             LM(j, 3) = 0.f;
         }
@@ -498,18 +510,21 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
 #undef LKP
 #undef LKH
 #undef LM
-    // ---- fault guard
+    // ---- what PhysX does with a runaway body (asset options max_linear_velocity / max_angular_velocity, legged_robot.py:701-702):
+    // it clamps the velocity and carries on.  The guard is for non-finite state only: such an env keeps its pose, is brought to
+    // rest and is reported, and the post-step terminates and resets it.
     float chk = pdot(velf0, velf0);
 #pragma unroll
     for (int j = 0; j < J; ++j) chk += qdf[j] * qdf[j] * 1e-4f;
     chk = pleg_sum<L>(chk);
-    if (!ok || !(chk < 2.0e4f)) {
+    if (!ok || !(chk < 3.0e38f)) {
 #pragma unroll
         for (int j = 0; j < J; ++j) qd[j] = 0.f;
 #pragma unroll
         for (int k = 7; k < 13; ++k) root[k] = 0.f;
-        return true;
+        return 1;
     }
+    int code = 0;
     PSTAMP(pr, 10);
     // ---- integrate (both lanes, identical)
 #pragma unroll
@@ -530,6 +545,11 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
     const V3 velf0o = px3(velf0);
     V3 wn = sel3(h, velf0o, velf0);
     V3 vn = sel3(h, velf0, velf0o) + dt * cross(wb, vb);
+    {   // the base's velocities as they are published, clamped at the asset's maxima (both lanes hold both and clamp alike)
+        const float w2 = dot(wn, wn), v2 = dot(vn, vn);
+        if (c.max_angular_velocity > 0.0f && w2 > c.max_angular_velocity * c.max_angular_velocity) { wn = (c.max_angular_velocity * rsqrtf(w2)) * wn; code = 2; }
+        if (c.max_linear_velocity > 0.0f && v2 > c.max_linear_velocity * c.max_linear_velocity) { vn = (c.max_linear_velocity * rsqrtf(v2)) * vn; code = 2; }
+    }
     V3 vw = mul(Rb, vn), ww = mul(Rb, wn);
     root[0] += dt * vw.x; root[1] += dt * vw.y; root[2] += dt * vw.z;
     root[7] = vw.x; root[8] = vw.y; root[9] = vw.z;
@@ -548,5 +568,5 @@ __device__ __forceinline__ bool physics_pair(const PhysCfg &c /* phys_cfg(P): re
 #pragma unroll
     for (int k = 0; k < 4; ++k) qq[k] = qn[k] * nrm;
     PSTAMP(pr, 11);
-    return false;
+    return code;
 }

@@ -41,7 +41,7 @@ struct Net {
     int dims[LG_PPO_MAX_LAYERS + 1];         // dims[0] = input, dims[nl] = output
     int64_t w_off[LG_PPO_MAX_LAYERS], b_off[LG_PPO_MAX_LAYERS];
     int64_t pl_off[LG_PPO_MAX_LAYERS];       // offset of this layer's weight matrix inside a bf16 plane (multiple of 8)
-    int pl_ld0;                              // row length of W_0's plane image: dims[0] rounded up to 8 (pad columns zero)
+    int pl_ld0;                              // row length of W_0's plane image: dims[0] rounded up to 32 = one k-tile (pad columns zero)
     float *act[LG_PPO_MAX_LAYERS + 1];       // act[l], l >= 1: output of layer l-1 (workspace, Mmax rows)
     float *dz[LG_PPO_MAX_LAYERS + 1];        // gradient wrt act[l] pre-activation
 };
@@ -66,6 +66,9 @@ struct lg_ppo {
     lg_comm *comm;                           // when set: gradients are reduced per layer inside the backward pass
     hipEvent_t ev_bucket;                    // a layer's weight gradients are complete on the side stream
     int comm_rc;
+    int comm_timing;                         // lg_ppo_comm_timing: event pairs around the wait for the last bucket
+    std::vector<hipEvent_t> comm_ev;         // [2 k], [2 k + 1]: before / after the wait of recorded minibatch k
+    size_t comm_ev_used;
     lg_ppo_cfg cfg;
     PpoDev dev;
     Net net[2];                              // 0 actor, 1 critic
@@ -117,7 +120,7 @@ static int launch_ok() {
 }
 
 // forward of the selected nets on M rows.  in[z] = input of net z.  mask bit z selects the net.
-// in_pad: the inputs are the minibatch gathers, rows padded to a multiple of 8 floats (PpoDev::Op / OCp); otherwise rows of dims[0]
+// in_pad: the inputs are the minibatch gathers, rows padded to a multiple of 32 floats (PpoDev::Op / OCp); otherwise rows of dims[0]
 static void forward(lg_ppo *p, int M, const float *in0, const float *in1, int mask, int skip_head = 0, bool planes = false,
                     bool in_pad = false, hipStream_t on = nullptr, int l_begin = 0, int l_end = 1 << 30) {
     const hipStream_t fs = on ? on : p->stream;
@@ -295,8 +298,14 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         if (early) (void)hipStreamWaitEvent(p->stream, p->ev_side2, 0);
     }
     if (p->comm) {                                   // ... and every reduced bucket
+        const bool rec = p->comm_timing && p->comm_ev_used + 2 <= 2 * 4096;
+        if (rec) {
+            while (p->comm_ev.size() < p->comm_ev_used + 2) { hipEvent_t e; (void)hipEventCreate(&e); p->comm_ev.push_back(e); }
+            (void)hipEventRecord(p->comm_ev[p->comm_ev_used], p->stream);
+        }
         (void)hipEventRecord(lg_comm_event_(p->comm), lg_comm_stream_(p->comm));
         (void)hipStreamWaitEvent(p->stream, lg_comm_event_(p->comm), 0);
+        if (rec) { (void)hipEventRecord(p->comm_ev[p->comm_ev_used + 1], p->stream); p->comm_ev_used += 2; }
     }
 }
 
@@ -324,6 +333,7 @@ int lg_ppo_destroy(lg_ppo *p) {
     if (p->ev_dz) (void)hipEventDestroy(p->ev_dz);
     if (p->ev_side) (void)hipEventDestroy(p->ev_side);
     if (p->ev_bucket) (void)hipEventDestroy(p->ev_bucket);
+    for (hipEvent_t e : p->comm_ev) (void)hipEventDestroy(e);
     for (void *q : p->allocs) (void)hipFree(q);
     delete p;
     return 0;
@@ -357,7 +367,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
         lg_set_error("stream/event creation failed"); delete p; return -100;
     }
     p->step = 0; p->inject = 0; p->act_count = 0; p->update_count = 0; p->params_dirty = 1;
-    p->comm = nullptr; p->comm_rc = 0;
+    p->comm = nullptr; p->comm_rc = 0; p->comm_timing = 0; p->comm_ev_used = 0;
     p->env = nullptr; p->pp_pending = 0;
     if (getenv("LG_XCD_REMAP")) ppok_debug_set_xcd_remap(atoi(getenv("LG_XCD_REMAP")));
     if (getenv("LG_DW_T")) ppok_debug_set_dw_t(atoi(getenv("LG_DW_T")));
@@ -392,8 +402,9 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
                 n.pl_off[l] = po;
                 d.seg_off[d.nseg] = n.w_off[l]; d.seg_pl[d.nseg] = po;
                 d.seg_rows[d.nseg] = n.dims[l + 1]; d.seg_cols[d.nseg] = n.dims[l];
-                // rows of the first layer's image padded to whole 16-byte chunks (the observation width need not be one)
-                const int ld = l == 0 ? (n.dims[0] + 7) / 8 * 8 : n.dims[l];
+                // rows of the first layer's image padded to whole k-tiles of 32 (the observation width need not be one: 48, 235, 169, 65):
+                // the LDS-DMA forward (ppo_gemm_glds.h) moves whole k-tiles, the plane path of k_gemm whole 16-byte chunks
+                const int ld = l == 0 ? (n.dims[0] + 31) / 32 * 32 : n.dims[l];
                 if (l == 0) n.pl_ld0 = ld;
                 seg_ld[d.nseg] = ld;
                 ++d.nseg;
@@ -404,7 +415,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     d.off_bias_actor_head = (int)p->net[0].b_off[p->net[0].nl - 1];
     d.off_bias_critic_head = (int)p->net[1].b_off[p->net[1].nl - 1];
     d.N = N; d.T = T; d.A = A; d.O = O; d.OC = OC; d.mb_rows = R;
-    d.Op = (O + 7) / 8 * 8; d.OCp = (OC + 7) / 8 * 8;
+    d.Op = (O + 31) / 32 * 32; d.OCp = (OC + 31) / 32 * 32;
     d.world = cfg->world_size > 0 ? cfg->world_size : 1;
     d.env_offset = 0;
     d.adaptive = cfg->adaptive_schedule; d.clipped_value = cfg->use_clipped_value_loss;
@@ -683,6 +694,19 @@ int lg_ppo_end_update(lg_ppo *p) { p->step = 0; return 0; }
 int lg_ppo_set_comm(lg_ppo *p, lg_comm *c) {
     if (c && p->dev.det64) { lg_set_error("gradient buckets inside the backward pass cannot be combined with deterministic mode"); return -14; }
     p->comm = c;
+    return 0;
+}
+int lg_ppo_comm_timing(lg_ppo *p, int enable) { p->comm_timing = enable ? 1 : 0; return 0; }
+int lg_ppo_comm_wait_ms(lg_ppo *p, double *ms_total, int64_t *minibatches) {
+    if (!ms_total || !minibatches) { lg_set_error("null argument"); return -1; }
+    (void)hipStreamSynchronize(p->stream);
+    double sum = 0.0;
+    for (size_t k = 0; k + 1 < p->comm_ev_used; k += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->comm_ev[k], p->comm_ev[k + 1]) == hipSuccess) sum += ms;
+    }
+    *ms_total = sum; *minibatches = (int64_t)(p->comm_ev_used / 2);
+    p->comm_ev_used = 0;
     return 0;
 }
 int lg_ppo_allreduce_adv_moments(lg_ppo *p, lg_comm *c) { return lg_comm_allreduce_sum(c, p->dev.adv_partial, 4, p->stream); }

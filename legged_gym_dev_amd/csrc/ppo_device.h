@@ -14,7 +14,7 @@ struct GemmArgs {                  // up to 2 problems per launch (actor, critic
     const uint16_t *Bpl[2];
     int64_t pl_stride;
     // first layer on a padded minibatch (observation width not a multiple of 8: 235, 169, 65): the plane image of W_0 and the
-    // gathered observations both have rows of Kpl = ldbpl = width rounded up to 8 with zero pad columns, so the plane path runs on
+    // gathered observations both have rows of Kpl = ldbpl = width rounded up to 32 with zero pad columns, so the plane path runs on
     // whole 16-byte chunks; K / ldb above stay the true width for the fp32-operand fallback.  0 = same as K / ldb.
     int Kpl[2], ldbpl[2];
     // weight gradient against the padded observations: N = padded width is computed, nstore (true width, row length of C) is stored
@@ -45,7 +45,7 @@ struct PpoDev {                    // passed by value to kernels
     int32_t *perm;
     float *adv_partial;
     float *mb_obs, *mb_critic_obs, *mb_actions, *mb_mu, *mb_scalars;   // minibatch gathers; scalars = [v_old, ret, adv, logp_old]
-    int Op, OCp;                   // row length of mb_obs / mb_critic_obs: O / OC rounded up to 8 (pad columns stay zero)
+    int Op, OCp;                   // row length of mb_obs / mb_critic_obs: O / OC rounded up to 32 = one k-tile (pad columns stay zero)
     float *cur_reward_sum, *cur_episode_len, *ep_stats, *ep_ring;      // ep_ring (2, 100): last finished episodes' return / length
     int32_t *ep_ring_count;
     float *head_part;              // scratch rows of k_head_net (one per workgroup), folded by k_head_finish

@@ -1045,11 +1045,22 @@ static int g_gemm_t96 = 0;     // 96x128 tile where it fills the 512 workgroup s
                                // (the side stream's weight-gradient GEMMs already fill the idle slots); kept for A/B
 extern "C" void ppok_debug_set_t96(int v) { g_gemm_t96 = v; }
 
+#include "ppo_gemm_glds.h"
+
 static const int g_gemm_ldb = getenv("LG_GEMM_LDB") ? atoi(getenv("LG_GEMM_LDB")) : 0;
 template <int EPI, bool B_RC = true, int PL = 1>
 static void launch_gemm_pl(const GemmArgs &g, int nz, hipStream_t s) {
     int maxM = 0, maxN = 0;
     for (int z = 0; z < nz; ++z) { maxM = g.M[z] > maxM ? g.M[z] : maxM; maxN = g.N[z] > maxN ? g.N[z] : maxN; }
+    if constexpr (EPI == 0 && PL == 1) {
+        // LDS-DMA forward (ppo_gemm_glds.h): 40 KB workgroups, up to four per CU.  LG_GEMM_GLDS=0: the register-staged k_gemm (A/B)
+        static const int glds = getenv("LG_GEMM_GLDS") ? atoi(getenv("LG_GEMM_GLDS")) : 1;
+        if (glds && maxM > 64 && glds_ok(g, nz)) {
+            dim3 grid((unsigned)(((maxM + GLDS_BM - 1) / GLDS_BM) * (maxN / GLDS_BN)), 1, nz);
+            hipLaunchKernelGGL(k_gemm_glds_fwd, grid, dim3(256), 0, s, g);
+            return;
+        }
+    }
     const long big_tiles = (long)((maxM + 127) / 128) * ((maxN + 127) / 128);
     if (big_tiles >= 192 && maxN > 64 && maxM > 64) {
         // 256 CUs x 2 resident workgroups: time ~ rounds x tile area.  24576 rows in 128-row tiles give 768 or 384

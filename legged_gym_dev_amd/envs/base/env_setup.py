@@ -16,6 +16,7 @@ import os
 import numpy as np
 
 from legged_gym_dev_amd import capi
+from legged_gym_dev_amd.envs.base import cfg_contract
 from legged_gym_dev_amd.utils.helpers import class_to_dict
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "assets")
@@ -71,6 +72,7 @@ class EnvSetup:
 
     def __init__(self, cfg, cm: dict, sim_dt: float, terrain=None, env_offset=0, total_envs=None, seed=1, extra_terms=None):
         self.cfg, self.cm = cfg, cm
+        cfg_contract.enforce(cfg)                           # no silently ignored field: refusals and one-time warnings (cfg_contract.py)
         self.extra_terms = dict(extra_terms or {})          # name -> reward_terms._Term (declared by the env class)
         A, B = cm["num_dofs"], cm["num_bodies"]
         self.num_envs = N = cfg.env.num_envs
@@ -406,7 +408,11 @@ class EnvSetup:
             c.dof_pos_limits[d][0], c.dof_pos_limits[d][1] = float(self.dof_pos_limits[d, 0]), float(self.dof_pos_limits[d, 1])
         _fill(c.dof_vel_limits, self.dof_vel_limits.tolist())
         _fill(c.torque_limits, self.torque_limits.tolist())
-        _fill(c.gravity, [float(g) for g in cfg.sim.gravity])
+        # asset options the reference hands to the simulator (legged_robot.py:692-705)
+        _fill(c.gravity, [0.0, 0.0, 0.0] if cfg.asset.disable_gravity else [float(g) for g in cfg.sim.gravity])
+        c.max_linear_velocity, c.max_angular_velocity = float(cfg.asset.max_linear_velocity), float(cfg.asset.max_angular_velocity)
+        c.armature = float(cfg.asset.armature)
+        c.rest_offset = float(cfg.asset.thickness) + float(getattr(physx, "rest_offset", 0.0))
         c.ground_friction = float(cfg.terrain.static_friction)
         c.contact_offset = float(getattr(physx, "contact_offset", 0.01))
         c.max_depenetration_velocity = float(getattr(physx, "max_depenetration_velocity", 1.0))

@@ -50,7 +50,8 @@ def draw_env_constants(cfg, num_envs_total, body0_mass, terrain, num_shapes=0):
                    for k in ("restitution", "compliance", "thickness")]
     if any(f for _, f, _ in shape_flags) and num_shapes <= 0:
         raise ValueError("rigid-shape randomisation needs the asset's shape count (model['num_shapes'])")
-    shape_props = np.zeros((N, max(num_shapes, 1), 3), dtype=np.float64)     # the asset defaults: 0
+    shape_props = np.zeros((N, max(num_shapes, 1), 3), dtype=np.float64)     # the asset defaults: restitution 0, compliance 0,
+    shape_props[:, :, 2] = float(getattr(cfg.asset, "thickness", 0.0))         # thickness = asset option (legged_robot.py:704)
     inv_mass = np.zeros(N, dtype=np.float64)
     start = origins.clone()                                # actor start position: env origin + U(-1, 1) in xy (:739-741)
     for i in range(N):
@@ -79,6 +80,7 @@ def draw_env_constants(cfg, num_envs_total, body0_mass, terrain, num_shapes=0):
     # The sphere-set contact model carries one material per robot: the mean over the robot's shapes.
     mat = np.zeros((N, 4), np.float32)
     mat[:, :3] = shape_props.mean(1)
+    mat[:, 2] += float(getattr(cfg.sim.physx, "rest_offset", 0.0))            # the env's rest offset: shape thickness + the scene's
     mat[:, 3] = inv_mass
     out["material"] = torch.from_numpy(mat)
     return out
@@ -131,6 +133,7 @@ class LeggedRobot(BaseTask):
         self.rigid_shape_props = consts["shape_props"][lo:hi]          # (n, shapes, [restitution, compliance, thickness]) as drawn
         self.base_inv_mass = consts["base_inv_mass"][lo:hi]
         self.fault_total, self.n_fault = t["fault_total"], t["n_fault"]
+        self.vel_clamp_total, self.n_vel_clamp = t["vel_clamp_total"], t["n_vel_clamp"]    # base-velocity clamps (asset.max_*_velocity)
         if "terrain_levels" in consts:
             t["terrain_levels"].copy_(consts["terrain_levels"][lo:hi])
             t["terrain_types"].copy_(consts["terrain_types"][lo:hi])

@@ -129,6 +129,10 @@ def load_urdf(path: str, collapse_fixed_joints: bool = True,
             s = _parse_shape(col)
             if s is not None:
                 lk.shapes.append(s)
+        if ine is None and lk.shapes:
+            # Isaac Gym would give such a link the mass of its shapes at asset.density (legged_robot.py:698); not implemented
+            raise NotImplementedError(f"link {lk.name!r} has collision geometry but no <inertial>: deriving its mass from "
+                                      "cfg.asset.density is not implemented")
         links[lk.name] = lk
 
     has_parent = set()

@@ -177,6 +177,20 @@ class HipPPO:
             self.param_views[k].copy_(v.to(self.device))
         self.params_changed()
 
+    def comm_timing(self, enable):
+        """lg_ppo_comm_timing: record the learner stream's wait for the gradient buckets (NativeComm) of every minibatch."""
+        self.lib.lg_ppo_comm_timing.argtypes = [C.c_void_p, C.c_int]
+        self.lib.lg_ppo_comm_timing(self.ctx, int(bool(enable)))
+
+    def comm_wait_ms(self):
+        """(total ms the learner's stream waited for reduced buckets, minibatches recorded) since the last call; synchronises."""
+        ms, n = C.c_double(), C.c_int64()
+        self.lib.lg_ppo_comm_wait_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        rc = self.lib.lg_ppo_comm_wait_ms(self.ctx, C.byref(ms), C.byref(n))
+        if rc != 0:
+            raise LeggedHipError(f"lg_ppo_comm_wait_ms failed ({rc}): {self.lib.lg_last_error().decode()}")
+        return float(ms.value), int(n.value)
+
     def attach_env(self, core):
         """lg_ppo_attach_env: ``core`` = the env's HipEnvCore (or None to detach, which runs whatever is still pending)."""
         self._call("attach_env", core.ctx if core is not None else None)

@@ -62,7 +62,7 @@ int lgo_create(const lg_cfg *cfg, const lg_model *model, const int16_t *height_s
     e->reset.assign(N, 1); e->time_out.assign(N, 0); e->last_contacts.assign((size_t)N * F, 0);
     e->extras_time_outs.assign(N, 0); e->fault.assign(N, 0); e->ep_len.assign(N, 0); e->terrain_levels.assign(N, 0);
     e->terrain_types.assign(N, 0); e->inj_levels.assign(N, 0); e->n_reset.assign(1, 0);
-    e->n_fault.assign(1, 0); e->fault_total.assign(1, 0);
+    e->n_fault.assign(1, 0); e->fault_total.assign(1, 0); e->n_vel_clamp.assign(1, 0); e->vel_clamp_total.assign(1, 0);
     *out = e;
     return 0;
 }
@@ -85,6 +85,7 @@ int lgo_get_buffers(void *ctx, lg_buffers *b) {
     b->extras_episode = e->extras_episode.data(); b->extras_terrain_level = e->extras_terrain_level.data();
     b->extras_time_outs = e->extras_time_outs.data(); b->n_reset = e->n_reset.data();
     b->extras_episode_acc = e->extras_episode_acc.data(); b->n_fault = e->n_fault.data(); b->fault_total = e->fault_total.data();
+    b->n_vel_clamp = e->n_vel_clamp.data(); b->vel_clamp_total = e->vel_clamp_total.data();
     b->tg_state = e->tg_state.data(); b->tg_traj = e->tg_traj.data(); b->trajectory = e->trajectory.data();
     b->prev_error = e->prev_error.data(); b->push_timer = e->push_timer.data();
     b->inject_uniforms = e->inj_u.data(); b->inject_levels = e->inj_levels.data(); b->material = e->material.data();

@@ -50,8 +50,9 @@ struct Env {
         tg_state, tg_traj, trajectory, prev_error, push_timer;
     std::vector<uint8_t> reset, time_out, last_contacts, extras_time_outs, fault;
     std::vector<int64_t> ep_len, terrain_levels, terrain_types, inj_levels;
-    std::vector<int32_t> n_reset, n_fault;
-    std::vector<int64_t> fault_total;
+    std::vector<int32_t> n_reset, n_fault, n_vel_clamp;
+    std::vector<int64_t> fault_total, vel_clamp_total;
+    int clamp_count = 0;                         // base-velocity clamps since the last finalize (lgo_physics.cpp)
     std::vector<float> material;                 // (N, 4): restitution, compliance, thickness, inverse base mass
     int64_t step_counter = 0;
     int init_done = 1, inject = 0;

@@ -395,6 +395,7 @@ void post_physics_step(Env &e) {
     for (int i = 0; i < N; ++i) n_fault += was_fault[i];
     e.n_fault[0] = n_fault;
     e.fault_total[0] += n_fault;
+    e.n_vel_clamp[0] = e.clamp_count; e.vel_clamp_total[0] += e.clamp_count; e.clamp_count = 0;
     if (n_reset > 0) {
         for (int k = 0; k < LG_NUM_TERMS; ++k) {
             const float sc = k < LG_NUM_REWARDS ? c.rew_scale[k] : (k - LG_NUM_REWARDS < c.num_xterms ? c.xterms[k - LG_NUM_REWARDS].scale : 0.0f);

@@ -138,7 +138,7 @@ struct Contact {
     float lam[3], iW[3];
 };
 
-static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weight) {
+static int simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weight) {
     const lg_cfg &c = e.cfg;
     const lg_model &m = e.model;
     const int A = e.A, NL = A + 1;
@@ -189,7 +189,7 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     for (int d = A - 1; d >= 0; --d) {                                  // inward pass
         int l = d + 1, pl = par[d];
         U[d] = mul(IA[l], S[d]);
-        D[d] = sdot(S[d], U[d]);
+        D[d] = sdot(S[d], U[d]) + c.armature;                            // asset.armature (legged_robot.py:703)
         u[d] = (tau[d] - m.joint_damping[d] * dofs[2 * d + 1]) - sdot(S[d], pA[l]);
         float Uv[6] = {U[d].w.x, U[d].w.y, U[d].w.z, U[d].v.x, U[d].v.y, U[d].v.z};
         M6 Ia;
@@ -245,7 +245,7 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
         V3 cw = xw + mul(Rb, cbk);
         Ground g = ground_at(e, cw.x, cw.y);
         float gap = (cw.z - g.h) * g.n.z - m.sph_radius[k];
-        if (c.material_rand) gap -= mat[2];                              // shape thickness: the robot rests that far off the surface
+        gap -= c.material_rand ? mat[2] : c.rest_offset;                 // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
         if (gap >= c.contact_offset) continue;
         Contact &C = ct[nc++];
         C.link = l;
@@ -284,13 +284,23 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     Limit lm[LG_MAX_DOF];
     int nlim = 0;
     int lim_count[LG_MAX_DOF + 1] = {};                                // active limits per leg chain (Jacobi relaxation, as for contacts)
+    // The joint velocity limit rides in the same rows (a bound on the joint rate enforced by a joint-space impulse: equal and opposite
+    // on child and parent, so momentum is conserved -- the clamp at integration alone leaves the base the reaction of the rate it takes away).
     for (int d = 0; d < A; ++d) {
-        const float lo = m.q_lower[d], hi = m.q_upper[d];
-        if (!(hi > lo)) continue;
+        const float lo = m.q_lower[d], hi = m.q_upper[d], vlim = m.vel_limit[d];
         const float q = dofs[2 * d];
         float sgn = 0.0f, gap = 0.0f;
-        if (q + dt * qdf[d] > hi) { sgn = 1.0f; gap = hi - q; }
-        else if (q + dt * qdf[d] < lo) { sgn = -1.0f; gap = q - lo; }
+        if (hi > lo) {
+            if (q + dt * qdf[d] > hi) { sgn = 1.0f; gap = hi - q; }
+            else if (q + dt * qdf[d] < lo) { sgn = -1.0f; gap = q - lo; }
+        }
+        float vtarget = gap >= 0.0f ? -gap / dt : std::min(-gap * c.contact_erp / dt, c.max_depenetration_velocity);
+        if (vlim > 0.0f) {
+            if (sgn == 0.0f) {
+                if (qdf[d] > vlim) { sgn = 1.0f; vtarget = -vlim; }
+                else if (qdf[d] < -vlim) { sgn = -1.0f; vtarget = -vlim; }
+            } else vtarget = std::max(vtarget, -vlim);
+        }
         if (sgn == 0.0f) continue;
         float timp[LG_MAX_DOF] = {};
         timp[d] = 1.0f;
@@ -301,7 +311,7 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
         Limit &Lm = lm[nlim++];
         Lm.d = d; Lm.sgn = sgn; Lm.lam = 0.0f;
         Lm.iW = dq[d] > 1e-9f ? 1.0f / dq[d] : 0.0f;
-        Lm.vtarget = gap >= 0.0f ? -gap / dt : std::min(-gap * c.contact_erp / dt, c.max_depenetration_velocity);
+        Lm.vtarget = vtarget;
         lim_count[d / m.joints_per_leg]++;
     }
     for (int k = 0; k < nlim; ++k) lm[k].relax = 1.0f / (float)lim_count[lm[k].d / m.joints_per_leg];
@@ -353,15 +363,17 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
         cf_accum[3 * C.body + 1] += s * lw.y;
         cf_accum[3 * C.body + 2] += s * lw.z;
     }
-    // fault guard (same rule as the HIP kernel): NaN/Inf or an absurd base twist -> keep the pose, bring the
-    // env to rest, report the fault (the post-step then terminates and resets it)
+    // Same rule as the HIP kernels.  A runaway body: PhysX clamps its velocities at the asset options max_linear_velocity /
+    // max_angular_velocity (legged_robot.py:701-702) and carries on.  The guard is for non-finite state only: keep the pose, bring
+    // the env to rest, report the fault (the post-step then terminates and resets it).
     float chk = dot(velf[0].w, velf[0].w) + dot(velf[0].v, velf[0].v);
     for (int d = 0; d < A; ++d) chk += qdf[d] * qdf[d] * 1e-4f;
-    if (!ok || !(chk < 2.0e4f)) {
+    if (!ok || !(chk < 3.0e38f)) {
         for (int d = 0; d < A; ++d) dofs[2 * d + 1] = 0.0f;
         for (int k = 7; k < 13; ++k) root[k] = 0.0f;
-        return true;
+        return 1;
     }
+    int code = 0;
     for (int d = 0; d < A; ++d) {
         float v = qdf[d];
         if (m.q_upper[d] > m.q_lower[d]) {
@@ -377,6 +389,11 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
     }
     V3 wn = velf[0].w;
     V3 vn = velf[0].v + dt * cross(wb, vb);                            // classical velocity of the base origin
+    {   // the base's velocities as they are published, clamped at the asset's maxima
+        const float w2 = dot(wn, wn), v2 = dot(vn, vn);
+        if (c.max_angular_velocity > 0.0f && w2 > c.max_angular_velocity * c.max_angular_velocity) { wn = (c.max_angular_velocity / std::sqrt(w2)) * wn; code = 2; }
+        if (c.max_linear_velocity > 0.0f && v2 > c.max_linear_velocity * c.max_linear_velocity) { vn = (c.max_linear_velocity / std::sqrt(v2)) * vn; code = 2; }
+    }
     V3 vw = mul(Rb, vn), ww = mul(Rb, wn);
     root[0] += dt * vw.x; root[1] += dt * vw.y; root[2] += dt * vw.z;
     root[7] = vw.x; root[8] = vw.y; root[9] = vw.z;
@@ -393,7 +410,7 @@ static bool simulate_env(Env &e, int i, float dt, float *cf_accum, float cf_weig
                    q[3] * dq[3] - q[0] * dq[0] - q[1] * dq[1] - q[2] * dq[2]};
     float nrm = 1.0f / std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     for (int k = 0; k < 4; ++k) q[k] = qn[k] * nrm;
-    return false;
+    return code;
 }
 
 void simulate(Env &e) {
@@ -404,8 +421,14 @@ void simulate(Env &e) {
     for (int i = 0; i < N; ++i) {
         float *cf = &e.contact[(size_t)i * B * 3];
         for (int k = 0; k < 3 * B; ++k) cf[k] = 0.0f;
-        for (int s = 0; s < ns; ++s)
-            if (simulate_env(e, i, dt, cf, 1.0f / (float)ns)) e.fault[i] = 1;
+        for (int s = 0; s < ns; ++s) {
+            const int code = simulate_env(e, i, dt, cf, 1.0f / (float)ns);
+            if (code & 1) e.fault[i] = 1;
+            if (code & 2) {
+#pragma omp atomic
+                e.clamp_count += 1;
+            }
+        }
     }
 }
 

@@ -296,7 +296,8 @@ def test_shape_material_parameters_act_on_the_contacts(oracle_built):
     per robot, lg_buffers.material): thickness = rest offset (the stance settles that much higher), restitution = the contact leaves
     with e x its approach speed when that exceeds sim.physx.bounce_threshold_velocity (a dropped robot rebounds, e = 0 does not),
     compliance = constraint-force mixing on the normal row (a softer contact sinks deeper under the same weight).  Env 0 carries
-    the asset defaults (zeros) and must behave exactly as with the randomisation switched off."""
+    the asset defaults (restitution 0, compliance 0, thickness = cfg.asset.thickness) and must behave exactly as with the
+    randomisation switched off."""
     cfg = _cfg("anymal_c", n=4)
     cfg.control.control_type, cfg.control.action_scale = "P", 0.5
     rsp = cfg.domain_rand.rigid_shape_properties
@@ -307,7 +308,8 @@ def test_shape_material_parameters_act_on_the_contacts(oracle_built):
         assert env.setup.to_structs()[0].material_rand == 1 and ref.setup.to_structs()[0].material_rand == 0
         n, A = 4, cm["num_dofs"]
         mat = np.zeros((n, 4), np.float32)
-        mat[1, 2] = 0.02                                   # thickness
+        mat[:, 2] = cfg.asset.thickness                    # the asset option every shape starts from (legged_robot.py:704)
+        mat[1, 2] += 0.02                                  # thickness
         mat[2, 0] = 1.6                                    # restitution (combined with the plane's 0 by averaging: e = 0.8)
         mat[3, 1] = 2.0e-6                                 # compliance, m/N
         env.set("material", mat)
