@@ -361,7 +361,10 @@ int lg_ppo_end_update(lg_ppo *p);                  /* finalise mean losses, clea
  * leaves its single-workgroup epilogue pending and lg_ppo_process_env_step only records its arguments; both run inside the launch
  * of the NEXT lg_ppo_act (extra workgroups beside the two MLPs: 5 launches per policy step become 3).  Any other entry point of
  * either object, and lg_ppo_attach_env(p, NULL), first runs what is pending the ordinary way, so results are identical.
- * While attached, extras / n_reset / the logging sums of a step become visible with the next lg_ppo_act (or flush). */
+ * While attached, extras / n_reset / the logging sums of a step become visible with the next lg_ppo_act (or flush).
+ * Contract: env and learner run on the SAME stream (checked: the fused epilogue reads the env's step outputs in stream order), and
+ * the env outlives the attachment -- lg_destroy refuses an env that is still attached; detach with lg_ppo_attach_env(p, NULL) or
+ * destroy the learner first. */
 int lg_ppo_attach_env(lg_ppo *p, lg_ctx *env);
 /* The caller wrote lg_ppo_buffers.params itself (checkpoint load, a broadcast of its own): the weight images the rollout forward
  * reads are re-derived by the next lg_ppo_act.  (lg_ppo_minibatch_step and lg_ppo_broadcast_params mark them stale themselves.) */

@@ -48,6 +48,8 @@ int lg_version(void) { return 1; }
 
 int lg_destroy(lg_ctx *c) {
     if (!c) return 0;
+    // a learner attached with lg_ppo_attach_env holds this pointer (and a pending epilogue): detach it first
+    if (c->defer_finalize) { g_err = "lg_destroy: a learner is still attached (lg_ppo_attach_env(p, NULL) or lg_ppo_destroy first)"; return -20; }
     if (c->d) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->n_allocs; ++i) (void)hipFree(c->allocs[i]);
     delete c;

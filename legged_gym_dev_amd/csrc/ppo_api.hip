@@ -51,6 +51,7 @@ struct lg_ctx;
 extern "C" {
 // env side of the fused rollout epilogue (env_api.hip; same library, not in the header)
 void lg_internal_defer_finalize(lg_ctx *c, int on);
+hipStream_t lg_internal_stream(lg_ctx *c);
 int lg_internal_finalize_pending(lg_ctx *c);
 const DevParams *lg_internal_take_finalize(lg_ctx *c, int64_t *counter);
 const DevParams *lg_internal_host_params(lg_ctx *c);
@@ -74,11 +75,9 @@ struct lg_ppo {
     Net net[2];                              // 0 actor, 1 critic
     hipStream_t stream;
     hipStream_t side;                        // weight-gradient GEMMs run here, overlapping the input-gradient chain
-    hipStream_t side2;                       // the first layer's weight gradient over the rows the layer-2 input gradient has produced already
-    hipEvent_t ev_dz, ev_side, ev_half, ev_side2;
+    hipEvent_t ev_dz, ev_side;
     int overlap;
     long long *det_buf;                      // fixed-point shadow of the accumulators (lg_ppo_set_deterministic); dev.det64 = it when on
-    int dw0_early;                           // LG_DW0_EARLY (backward())
     int act_code;                            // kernels' activation code = cfg.activation + 1 (0 is 'none')
     int grads_dirty;
     // fused rollout epilogue (lg_ppo_attach_env): a process_env_step recorded for the next act launch
@@ -186,12 +185,6 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
         g.det_base = p->dev.grads; g.det64 = p->dev.det64; g.det_n = p->dev.num_params + 2;
     };
     const int nl = p->net[0].nl;
-    // LG_DW0_EARLY (A/B, off: the backward phase is bound by total machine work, co-running a third kernel only redistributes it --
-    // 0.486 vs 0.475 ms per minibatch, profiles/r03_ab.txt): the last weight gradient (layer 0) runs alone at the tail re-reading dz_1.  The layer-1 input gradient is launched as two row halves instead; the layer-0 weight
-    // gradient of the first half (its reduction runs over rows) starts on a third stream as soon as that half exists, beside the
-    // second half and the layer-1 weight gradient; only the second half's is left for the tail.
-    const int half = (M / 2) & ~255;
-    const bool early = p->dw0_early && p->overlap && !p->comm && nl >= 2 && half >= 2048;
     for (int l = nl - 1 - skip_head; l >= 0; --l) {
         GemmArgs g;
         memset(&g, 0, sizeof(g));
@@ -231,13 +224,6 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
             (void)hipEventRecord(p->ev_dz, p->stream);
             (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
         }
-        if (l == 0 && early) {                       // rows [half, M): the first half went out beside the layer-1 input gradient
-            for (int z = 0; z < 2; ++z) {
-                g.A[z] += (size_t)half * g.lda[z]; g.B[z] += (size_t)half * g.ldb[z]; g.K[z] = M - half;
-            }
-            int s2 = splits / 2 >= 8 ? (splits / 2) & ~7 : (splits / 2 > 0 ? splits / 2 : 1);
-            ppok_gemm_dw(&g, 2, s2, dw_stream);
-        } else
         ppok_gemm_dw(&g, 2, splits, dw_stream);
         if (p->comm) reduce_layer_bucket(p, l, dw_stream);
         if (l > 0) {                                 // dz[l] = (dz[l+1] . W_l) * act'(act[l]); db_{l-1} = colsum(dz[l])
@@ -255,47 +241,12 @@ static void backward(lg_ppo *p, int M, const float *in0, const float *in1, int s
             }
             g.elu = p->act_code;                         // derivative of the hidden activation, through its output act[l]
             g.pl_stride = p->dev.pl_stride;
-            if (l == 1 && early) {
-                GemmArgs h0 = g, h1 = g;
-                for (int z = 0; z < 2; ++z) {
-                    h0.M[z] = half;
-                    h1.M[z] = M - half;
-                    h1.A[z] += (size_t)half * g.lda[z]; h1.C[z] += (size_t)half * g.ldc[z]; h1.aux[z] += (size_t)half * g.ldaux[z];
-                }
-                ppok_gemm_dx(&h0, 2, p->stream);
-                (void)hipEventRecord(p->ev_half, p->stream);
-                (void)hipStreamWaitEvent(p->side2, p->ev_half, 0);
-                GemmArgs w;                              // dW_0 over rows [0, half)
-                memset(&w, 0, sizeof(w));
-                det_args(w);
-                long tiles = 0;
-                for (int z = 0; z < 2; ++z) {
-                    Net &n = p->net[z];
-                    w.A[z] = n.dz[1]; w.lda[z] = n.dims[1];
-                    w.B[z] = in[z]; w.ldb[z] = z == 0 ? p->dev.Op : p->dev.OCp;
-                    w.C[z] = p->dev.grads + n.w_off[0]; w.ldc[z] = n.dims[0];
-                    w.M[z] = n.dims[1]; w.N[z] = n.dims[0]; w.K[z] = half;
-                    if (w.ldb[z] != n.dims[0]) { w.N[z] = w.ldb[z]; w.nstore[z] = n.dims[0]; }
-                    const int tile = (w.M[z] > 64 && w.N[z] > 64) ? 128 : 64;
-                    long t = (long)((w.M[z] + tile - 1) / tile) * ((w.N[z] + tile - 1) / tile);
-                    tiles = t > tiles ? t : tiles;
-                }
-                static const int dw_target = getenv("LG_DW_WGS") ? atoi(getenv("LG_DW_WGS")) : 384;
-                int s0 = (int)((dw_target / 2 + tiles - 1) / tiles);
-                if (s0 > half / 256) s0 = half / 256;
-                if (s0 >= 8) s0 &= ~7;
-                if (s0 < 1) s0 = 1;
-                ppok_gemm_dw(&w, 2, s0, p->side2);
-                (void)hipEventRecord(p->ev_side2, p->side2);
-                ppok_gemm_dx(&h1, 2, p->stream);
-            } else
             ppok_gemm_dx(&g, 2, p->stream);
         }
     }
     if (p->overlap) {                                // join: the optimiser step (main stream) needs every dW
         (void)hipEventRecord(p->ev_side, p->side);
         (void)hipStreamWaitEvent(p->stream, p->ev_side, 0);
-        if (early) (void)hipStreamWaitEvent(p->stream, p->ev_side2, 0);
     }
     if (p->comm) {                                   // ... and every reduced bucket
         const bool rec = p->comm_timing && p->comm_ev_used + 2 <= 2 * 4096;
@@ -327,9 +278,6 @@ int lg_ppo_destroy(lg_ppo *p) {
     if (!p) return 0;
     if (p->env) { flush_rollout_epilogue(p); lg_internal_defer_finalize(p->env, 0); p->env = nullptr; }
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
-    if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); }
-    if (p->ev_half) (void)hipEventDestroy(p->ev_half);
-    if (p->ev_side2) (void)hipEventDestroy(p->ev_side2);
     if (p->ev_dz) (void)hipEventDestroy(p->ev_dz);
     if (p->ev_side) (void)hipEventDestroy(p->ev_side);
     if (p->ev_bucket) (void)hipEventDestroy(p->ev_bucket);
@@ -356,11 +304,7 @@ int lg_ppo_create(const lg_ppo_cfg *cfg, lg_ppo **out) {
     p->act_code = cfg->activation + 1;
     p->fused_act = getenv("LG_FUSED_ACT") ? atoi(getenv("LG_FUSED_ACT")) : 1;   // one-launch rollout forward (ppo_mlp_fused.hip) when the shape allows
     p->overlap = getenv("LG_PPO_OVERLAP") ? atoi(getenv("LG_PPO_OVERLAP")) : 1;
-    p->dw0_early = getenv("LG_DW0_EARLY") ? atoi(getenv("LG_DW0_EARLY")) : 0;   // measured slower: 0.486 vs 0.475 ms per minibatch
     if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_half, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_side2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_dz, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_bucket, hipEventDisableTiming) != hipSuccess) {
@@ -501,7 +445,6 @@ int lg_ppo_get_buffers(lg_ppo *p, lg_ppo_buffers *out) { *out = p->pub; return 0
 int lg_ppo_set_stream(lg_ppo *p, void *s) { p->stream = (hipStream_t)s; return 0; }
 int lg_ppo_inject_noise(lg_ppo *p, int enable) { p->inject = enable; return 0; }
 int lg_ppo_debug_set_overlap(lg_ppo *p, int v) { p->overlap = v; return 0; }
-int lg_ppo_debug_set_dw0_early(lg_ppo *p, int v) { p->dw0_early = v; return 0; }
 int lg_ppo_debug_set_fused_act(lg_ppo *p, int v) { p->fused_act = v && p->mlp.wfrag; return 0; }
 int lg_ppo_debug_get_fused_act(lg_ppo *p) { return p->fused_act; }          // 1: lg_ppo_act runs the one-launch forward for this shape
 int lg_ppo_debug_set_act_count(lg_ppo *p, long long v) { p->act_count = v; return 0; }   // replay the same Philox draws (tests)
@@ -528,6 +471,8 @@ int lg_ppo_attach_env(lg_ppo *p, lg_ctx *env) {
     p->env = nullptr;
     if (env) {
         if (lg_internal_host_params(env)->cfg.num_envs != p->cfg.num_envs) { lg_set_error("lg_ppo_attach_env: env and learner differ in num_envs"); return -12; }
+        // the fused epilogue reads the env's rew / reset / time_out inside the learner's next act launch: only stream order makes that safe
+        if (lg_internal_stream(env) != p->stream) { lg_set_error("lg_ppo_attach_env: env and learner must run on the same stream (lg_set_stream / lg_ppo_set_stream)"); return -12; }
         p->env = env;
         lg_internal_defer_finalize(env, 1);
     }
@@ -538,8 +483,10 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
     if (p->step >= p->cfg.num_steps) { lg_set_error("Rollout buffer overflow"); return -10; }
     const float *cobs = critic_obs ? critic_obs : obs;
     int fused = -1;
-    const bool dirty = p->params_dirty != 0;
-    p->params_dirty = 0;
+    // rollout images of the weights (fragment-order image / bf16 planes) are rebuilt when the parameters changed since they were built AND
+    // at the first act of every rollout: a write through the zero-copy parameter views without lg_ppo_params_changed() is then stale for
+    // at most the rollout in progress.  The flag is cleared once the launch that consumed it has gone out.
+    const bool dirty = p->params_dirty != 0 || p->step == 0;
     if (p->fused_act) {
         // the image is rebuilt from the fp32 parameters whenever they changed since it was built (optimiser step, broadcast, or a
         // host write announced through lg_ppo_params_changed: checkpoint load, load_state_dict) -- also in the middle of a rollout
@@ -560,19 +507,26 @@ int lg_ppo_act(lg_ppo *p, const float *obs, const float *critic_obs) {
         } else flush_rollout_epilogue(p);
         fused = ppok_mlp_fwd(&g, &p->dev, 3, p->stream);
         if (fused != 0 && g.pp) { lg_set_error("fused act launch refused with a rollout epilogue attached"); return -13; }
-        if (fused == 0 && g.sample) { p->act_count++; return launch_ok(); }       // sampled and stored by the same launch
+        if (fused == 0 && g.sample) {                                             // sampled and stored by the same launch
+            p->act_count++;
+            const int rc = launch_ok();
+            if (rc == 0) p->params_dirty = 0;
+            return rc;
+        }
     }
     if (!p->fused_act) flush_rollout_epilogue(p);
     if (fused != 0) {
         // per-layer GEMMs on the optimiser's weight planes (no re-split of W per tile); same freshness rule as above
         static const int act_planes = getenv("LG_ACT_PLANES") ? atoi(getenv("LG_ACT_PLANES")) : 1;
-        if (act_planes && (dirty || p->step == 0)) ppok_sync_planes(&p->dev, p->stream);
+        if (act_planes && dirty) ppok_sync_planes(&p->dev, p->stream);
         forward(p, p->cfg.num_envs, obs, cobs, 3, 0, act_planes != 0);
     }
     ppok_act_sample(&p->dev, obs, cobs, p->net[0].act[p->net[0].nl], p->net[1].act[p->net[1].nl], p->step, p->act_count,
                     p->inject, p->stream);
     p->act_count++;
-    return launch_ok();
+    const int rc = launch_ok();
+    if (rc == 0) p->params_dirty = 0;
+    return rc;
 }
 
 int lg_ppo_process_env_step(lg_ppo *p, const float *rew, const uint8_t *dones, const uint8_t *time_outs) {
@@ -645,19 +599,6 @@ int lg_ppo_minibatch_backward(lg_ppo *p, int epoch, int mb) {
     // long pole (profiles/r02_timelines.txt) it is 9 us faster than head GEMM + k_loss + two head-gradient GEMMs (A/B on one box)
     static const int fuse128 = getenv("LG_HEAD_FUSE128") ? atoi(getenv("LG_HEAD_FUSE128")) : 1;
     const bool fuse = p->act_code == 1 && nl >= 2 && nc.dims[nl - 1] == H3 && (H3 == 64 || H3 == 32 || (H3 == 128 && fuse128));
-    // LG_FWD_SPLIT (A/B): the critic's forward chain on the side stream, one layer behind the actor's, so that the HBM-bound first
-    // layer of one net runs beside the MFMA-bound second layer of the other
-    static const int fwd_split = getenv("LG_FWD_SPLIT") ? atoi(getenv("LG_FWD_SPLIT")) : 0;
-    if (fwd_split && p->overlap && nc.nl == nl) {
-        const int sk = fuse ? 1 : 0;
-        forward(p, R, d.mb_obs, d.mb_critic_obs, 1, sk, true, true, p->stream, 0, fwd_split);
-        (void)hipEventRecord(p->ev_dz, p->stream);
-        (void)hipStreamWaitEvent(p->side, p->ev_dz, 0);
-        forward(p, R, d.mb_obs, d.mb_critic_obs, 2, sk, true, true, p->side);
-        forward(p, R, d.mb_obs, d.mb_critic_obs, 1, sk, true, true, p->stream, fwd_split);
-        (void)hipEventRecord(p->ev_side, p->side);
-        (void)hipStreamWaitEvent(p->stream, p->ev_side, 0);
-    } else
     forward(p, R, d.mb_obs, d.mb_critic_obs, 3, fuse ? 1 : 0, true, true);
     if (fuse) {
         ppok_head_fused(&d, H3, na.act[nl - 1], nc.act[nl - 1], na.dz[nl - 1], nc.dz[nl - 1], na.w_off[nl - 1], na.b_off[nl - 1],
@@ -740,59 +681,6 @@ int lg_ppo_debug_bucket_extents(lg_ppo *p, int l, int64_t *offsets, int64_t *cou
     const int n = bucket_extents(p, l, bufs, counts);
     for (int k = 0; k < n; ++k) offsets[k] = bufs[k] - p->dev.grads;
     return n;
-}
-
-// Timing experiment (tools/graph_period.py): the period of {minibatch_backward(mb 0), minibatch_step} launched `reps` times back to back on a
-// stream of its own -- directly, or as ONE captured hipGraph replayed `reps` times (the fork onto the side stream and the join become graph
-// edges).  Call inside an update (after lg_ppo_begin_update).  The repeated step reuses one gradient-norm slot, so the numbers the update
-// produces are meaningless; the launches, their sizes and their dependencies are the real ones.
-int lg_ppo_debug_graph_period(lg_ppo *p, int reps, int use_graph, float *us_out) {
-    hipStream_t s = nullptr, old = p->stream;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { lg_set_error("stream create failed"); return -100; }
-    (void)hipStreamSynchronize(old);
-    p->stream = s;
-    const int ga = p->gather_ahead;
-    p->gather_ahead = 0;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    int rc = 0;
-    auto one = [&]() { rc |= lg_ppo_minibatch_backward(p, 0, 0); rc |= lg_ppo_minibatch_step(p); p->update_count--; };
-    one();                                                     // warm-up (also leaves grads_dirty = 0)
-    (void)hipStreamSynchronize(s);
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    if (use_graph) {
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeGlobal) != hipSuccess) { lg_set_error("begin capture failed"); rc = -100; }
-        else {
-            one();
-            if (hipStreamEndCapture(s, &graph) != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                lg_set_error(std::string("graph capture / instantiate failed: ") + hipGetErrorString(hipGetLastError())); rc = -100;
-            }
-        }
-        if (!rc) { (void)hipGraphLaunch(exec, s); (void)hipStreamSynchronize(s); }
-    }
-    if (!rc) {
-        (void)hipEventRecord(e0, s);
-        for (int i = 0; i < reps; ++i) {
-            if (use_graph) (void)hipGraphLaunch(exec, s);
-            else one();
-        }
-        (void)hipEventRecord(e1, s);
-        (void)hipStreamSynchronize(s);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        *us_out = ms * 1e3f / (float)reps;
-    }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipStreamSynchronize(s);
-    if (p->side) (void)hipStreamSynchronize(p->side);
-    p->stream = old;
-    p->gather_ahead = ga;
-    p->mb_ready = -1;
-    (void)hipStreamDestroy(s);
-    return rc ? rc : launch_ok();
 }
 
 int lg_ppo_act_inference(lg_ppo *p, const float *obs, float *actions_out, int64_t rows) {

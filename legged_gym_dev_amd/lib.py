@@ -136,7 +136,9 @@ class HipEnvCore:
     def close(self):
         if getattr(self, "ctx", None):
             self.t = {}
-            self.lib.lg_destroy(self.ctx)
+            rc = self.lib.lg_destroy(self.ctx)
+            if rc != 0:                                   # e.g. a learner is still attached (lg_ppo_attach_env): the context stays alive
+                raise LeggedHipError(f"lg_destroy failed ({rc}): {self.lib.lg_last_error().decode()}")
             self.ctx = None
 
     def __del__(self):

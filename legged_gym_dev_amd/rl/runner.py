@@ -163,11 +163,14 @@ class OnPolicyRunner:
             if deferred:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
+                if pending:                              # the previous iteration's learning phase ends where this iteration begins: the
+                    pending[-1][2][2] = ev[0]            # log snapshot, its copy and any host gap count, and the times add up to wall time
                 self.rollout()
                 ev[1].record()
                 losses = ppo.update(self._grad_reduce)
-                ev[2].record()
-                pending.append((it, tot_iter, ev, self._log_snapshot(*losses)))
+                snap = self._log_snapshot(*losses)
+                ev[2].record()                           # (last iteration: after the snapshot's copy and the accumulator clears)
+                pending.append((it, tot_iter, ev, snap))
                 while len(pending) > 1:                  # the previous iteration's block, beside this iteration's GPU work
                     self._log(*pending.pop(0))
             else:
@@ -213,7 +216,8 @@ class OnPolicyRunner:
         ppo = self.ppo
         host, done, nacc = snap
         done.synchronize()
-        if isinstance(times, list):                       # HIP events on the learner's stream (all three have completed by now)
+        if isinstance(times, list):                       # HIP events on the learner's stream
+            times[2].synchronize()                        # (the next iteration's start event: recorded right behind the snapshot)
             collection_time, learn_time = times[0].elapsed_time(times[1]) * 1e-3, times[1].elapsed_time(times[2]) * 1e-3
         else:
             collection_time, learn_time = times

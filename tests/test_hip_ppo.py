@@ -632,47 +632,6 @@ def test_parameter_write_in_the_middle_of_a_rollout_reaches_act():
         hip.close()
 
 
-@pytest.mark.parametrize("O", [48, 235])
-def test_early_first_layer_weight_gradient_equals_the_tail_launch(O):
-    """LG_DW0_EARLY: the layer-1 input gradient as two row halves with the layer-0 weight gradient of the first half started on a third
-    stream beside the second, against the single launches (whole input gradient, whole weight gradient at the tail).  Same products,
-    only the split-K partition and the atomics' order differ: gradients agree to fp32 summation noise, and both match autograd."""
-    N, A, T = 1024, 12, 8                       # 2048 rows per minibatch x 4: half = 1024 ... use one minibatch of 8192 rows
-    alg = dict(ALG, num_mini_batches=1)
-    hip, ac, pt = _make(N, O, A, T, alg=alg)
-    try:
-        g = torch.Generator(device="cuda").manual_seed(12)
-        _fill_rollout(hip, ac, T, N, O, A, g)
-        hip.compute_returns(torch.randn(N, O, device="cuda", generator=g))
-        hip._call("begin_update")
-        grads = []
-        for early in (1, 0):
-            hip.lib.lg_ppo_debug_set_dw0_early(hip.ctx, early)
-            hip._call("minibatch_backward", 0, 0)
-            torch.cuda.synchronize()
-            grads.append(hip.t["grads"][: hip.num_params].clone())
-        a, b = grads
-        assert float((a - b).norm() / b.norm()) < 2e-6
-        w0 = hip.grad_views["actor.0.weight"]
-        assert float(w0.abs().max()) > 0
-        # against autograd
-        R = T * N
-        idx = hip.t["perm"].long()[:R]
-        flat = lambda name: hip.t[name].reshape(T * N, *hip.t[name].shape[2:])
-        algo = pt.PPO(ac, clip_param=0.2, value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-3, max_grad_norm=1.0,
-                      use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01)
-        batch = (flat("obs")[idx], flat("obs")[idx], flat("actions")[idx], flat("values")[idx].unsqueeze(-1),
-                 flat("advantages")[idx].unsqueeze(-1), flat("returns")[idx].unsqueeze(-1), flat("log_prob")[idx].unsqueeze(-1),
-                 flat("mu")[idx], hip.t["sigma"].clone().expand(R, A))
-        ac.zero_grad()
-        loss, kl, vl, sl = algo.minibatch_loss(*(x.clone() for x in batch))
-        loss.backward()
-        ref = torch.cat([p.grad.reshape(-1) for p in ac.parameters()])
-        assert float((a - ref).norm() / ref.norm()) < 3e-4
-    finally:
-        hip.close()
-
-
 def test_optimiser_step_equals_torch_adam_with_clip_and_adaptive_lr():
     """Known-answer test of lg_ppo_minibatch_step ("Adam step vs torch.optim.Adam"): the SAME gradients are written into
     the library's gradient buffer and into torch parameters' .grad; `clip_grad_norm_(max_grad_norm)` + `torch.optim.Adam.step()` with

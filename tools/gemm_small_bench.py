@@ -1,5 +1,5 @@
 """Per-k-tile cost of the 64x64 rollout configuration of k_gemm on the weight planes: forward GEMM of M rows, K swept
-(times are net of the plane split + a one-tile launch, i.e. relative; LG_GEMM_LDB=0/1 selects one or two LDS stages)."""
+(times are net of the plane split + a one-tile launch, i.e. relative; the two-stage variant LG_GEMM_LDB lives in the exp build: make exp EXPFLAGS=-DLG_EXP_KERNELS)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
