@@ -155,14 +155,16 @@ def test_two_rank_runner_over_gloo(task, tmp_path):
     assert bad.mean() < 3e-2, bad.mean()
 
 
-def test_two_ranks_in_deterministic_mode_equal_the_emulation_bit_for_bit(tmp_path, monkeypatch):
+@pytest.mark.parametrize("task", ["anymal_c_flat", "anymal_c_rough"])
+def test_two_ranks_in_deterministic_mode_equal_the_emulation_bit_for_bit(task, tmp_path, monkeypatch):
     """With LG_DETERMINISTIC=1 (lg_ppo_set_deterministic: fixed-point accumulation instead of float atomics) the comparison the
     test above can only make to an order of magnitude becomes exact: two processes over gloo and the in-process emulation hold
-    the same parameters, Adam moments and learning rate after two iterations on rough terrain, bit for bit."""
+    the same parameters, Adam moments and learning rate after two iterations, bit for bit -- on the flat task (BASELINE configs[1]:
+    actuator net, 48 observations) and on rough terrain.  A wrong `/world` on one layer or a dropped bucket cannot pass here."""
     monkeypatch.setenv("LG_DETERMINISTIC", "1")
     n, iters = 64, 2
-    a, b = _run_ranks(tmp_path, "anymal_c_rough", n, iters)
-    emu = _emulate("anymal_c_rough", n, iters)
+    a, b = _run_ranks(tmp_path, task, n, iters)
+    emu = _emulate(task, n, iters)
     np.testing.assert_array_equal(a["params"], b["params"])
     for key in ("params_it1", "params", "adam_m"):
         np.testing.assert_array_equal(emu[0][key], a[key], err_msg=key)
@@ -205,7 +207,12 @@ def test_bench_launches_its_own_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["roofline"]["bound"] == "mfma" and 0.0 < out["roofline"]["frac"] < 1.0     # the GEMM-group probe also runs with N > 1
-    assert out["config"]["num_envs_per_gpu"] == 256
+    assert out["config"]["num_envs_per_gpu"] == 256 and "LG_COMM=torch" in out["config"]["parallelism"]
+    # per-rank communication time and iteration time, so that a scaling loss on a real node can be attributed
+    cm = out["comm"]
+    assert len(cm["comm_ms_per_step_by_rank"]) == 2 and len(cm["iter_ms_by_rank"]) == 2 and cm["collectives_per_step"] == 20.0
+    assert all(0.0 < v < out["ms_per_step"] for v in cm["comm_ms_per_step_by_rank"])
+    assert cm["iter_ms_min"] <= cm["iter_ms_max"] <= out["ms_per_step"] * 1.05
     # a rank that dies takes the job down with a non-zero code
     env["LG_BENCH_FAIL_RANK"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",

@@ -567,8 +567,14 @@ def test_native_rccl_comm_single_rank():
                 hip.compute_returns(torch.randn(N, O, device="cuda", generator=g))
                 if attach:
                     comm.attach(hip)
+                    hip.comm_timing(True)              # lg_ppo_comm_timing: the learner stream's wait for the buckets, per minibatch
                 hip.update()
                 torch.cuda.synchronize()
+                if attach:                             # 2 epochs x 4 minibatches recorded; a one-rank wait is short but not negative
+                    ms, n = hip.comm_wait_ms()
+                    assert n == 8 and 0.0 <= ms < 50.0, (ms, n)
+                    assert hip.comm_wait_ms() == (0.0, 0)      # read clears
+                    hip.comm_timing(False)
                 outs.append(hip.t["params"][: hip.num_params].clone())
                 assert bool(torch.isfinite(outs[-1]).all())
                 if attach:
