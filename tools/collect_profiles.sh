@@ -1,5 +1,5 @@
-# One round's measurements on the GPU box:  bash tools/collect_profiles.sh r03   (then tools/digest_profiles.py r03 [r03_anymal_c_rough])
-TAG=${1:-r03}
+# One round's measurements on the GPU box:  bash tools/collect_profiles.sh r04   (then tools/digest_profiles.py r03 [r03_anymal_c_rough])
+TAG=${1:-r04}
 set -x
 cd $GRAFT_REPO_ROOT
 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
