@@ -326,8 +326,15 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
         tangents(nb, t1, t2);
         V3 dirs[3] = {nb, t1, t2};
         float Wc[3][3];
+#ifdef LG_EXP_W_DIRS                  // timing experiment only (make prof PROFFLAGS=-DLG_EXP_W_DIRS=1; wrong contact law): what the launch costs when
+        for (int a = 0; a < 3; ++a)   // the W phase computes 1 of its 3 test impulses -- the most a four-lane split of that phase could save
+            for (int b = 0; b < 3; ++b) Wc[b][a] = a == b ? 1.0f : 0.0f;
+#pragma unroll
+        for (int a = 0; a < LG_EXP_W_DIRS; ++a) {
+#else
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
+#endif
             V3 pAi = -1.0f * sel3(h, dirs[a], cross(Pc, dirs[a]));
             float ui[J];
 #pragma unroll

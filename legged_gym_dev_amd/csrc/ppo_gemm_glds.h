@@ -48,6 +48,12 @@ __device__ __forceinline__ void glds_split8(const float4 &lo, const float4 &hi, 
 template <int EPI, int B_PL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 0 ? 4 : 3, EPI == 0 ? 4 : 3))) k_gemm_glds(GemmArgs g) {
     static_assert((EPI == 0 && B_PL == 1) || (EPI == 1 && B_PL == 2), "forward on [n][k] planes, input gradient on the same planes read along their rows");
+#ifdef LG_EXP_GEMM_CLOCK             // diagnostic build only (make exp): in-kernel clock of the workgroups, s_memtime / s_memrealtime (as in k_gemm)
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+    struct ClkEnd { unsigned long long t0, r0; __device__ ~ClkEnd() {
+        const unsigned b = blockIdx.x + gridDim.x * blockIdx.z;
+        if (threadIdx.x == 0 && b < 2048) { g_gemm_clk[2 * b] = __builtin_amdgcn_s_memtime() - t0; g_gemm_clk[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - r0; } } } clk_end{clk_t0, clk_r0};
+#endif
     constexpr int NW = 4, GA = GLDS_BM / 8 / NW, GB = 3 * GLDS_BN / 16 / NW;       // DMA instructions per wave and k-tile: 4 + 6
     __shared__ __attribute__((aligned(1024))) unsigned char lds[GLDS_STAGE];
     const int z = blockIdx.z;
