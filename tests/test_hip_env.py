@@ -1124,6 +1124,19 @@ def test_hip_momentum_conserved_without_gravity():
     tpo.test_momentum_conserved_without_gravity(_HipBackend)
 
 
+def test_hip_momentum_conserved_with_joints_at_their_velocity_limit():
+    """Round 4's solver fix through lg_simulate: knees saturated at their velocity limit under 60 N m do not spin the base up."""
+    from tests import test_physics_oracle as tpo
+    tpo.test_momentum_conserved_with_joints_at_their_velocity_limit(_HipBackend)
+
+
+@pytest.mark.parametrize("robot", ["anymal_c", "cassie"])
+def test_hip_armature_adds_to_the_joint_space_inertia(robot):
+    """cfg.asset.armature through lg_simulate against the float64 mass-matrix formulation with armature on the joint diagonal."""
+    from tests import test_physics_oracle as tpo
+    tpo.test_armature_adds_to_the_joint_space_inertia(robot, _HipBackend)
+
+
 @pytest.mark.parametrize("robot,height", [("anymal_c", 0.56), ("cassie", 0.95), ("a1", 0.36)])
 def test_hip_static_stance_supports_weight(robot, height):
     """PD-held stance on the plane through lg_compute_torques + lg_simulate: the vertical contact forces add up to the robot's weight,

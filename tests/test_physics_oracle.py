@@ -106,8 +106,9 @@ def _advance(x, Rb, q, nu, eps):
     return x + eps * nu[:3], Rn, q + eps * nu[6:]
 
 
-def mass_matrix_dynamics(cm, x, quat, q, v_w, w_w, qd, tau, g):
-    """nu_dot for nu = [v_w, w_w, qd] from M nu_dot + h = tau_gen (float64)."""
+def mass_matrix_dynamics(cm, x, quat, q, v_w, w_w, qd, tau, g, armature=0.0):
+    """nu_dot for nu = [v_w, w_w, qd] from M nu_dot + h = tau_gen (float64).  armature: the asset option (legged_robot.py:703), a
+    reflected rotor inertia added to the joint-space inertia of every joint."""
     A = cm["num_dofs"]
     Rb = _quat_mat(quat)
     nu = np.concatenate([v_w, w_w, qd])
@@ -123,6 +124,7 @@ def mass_matrix_dynamics(cm, x, quat, q, v_w, w_w, qd, tau, g):
         dJw = (Jwp - Jwm) / (2 * eps) @ nu
         w = Jw @ nu
         h += Jv.T @ (m * dJv - m * g) + Jw.T @ (Iw @ dJw + np.cross(w, Iw @ w))
+    M[6:, 6:] += armature * np.eye(A)
     tg = np.concatenate([np.zeros(6), tau])
     return np.linalg.solve(M, tg - h), M
 
@@ -176,6 +178,43 @@ def test_free_dynamics_match_mass_matrix_formulation(robot, oracle_built):
         env.close()
 
 
+@pytest.mark.parametrize("robot", ["anymal_c", "cassie"])
+def test_armature_adds_to_the_joint_space_inertia(robot, oracle_built):
+    """cfg.asset.armature (legged_robot.py:703, default 0) against the float64 mass-matrix formulation with armature on the joint
+    diagonal: one substep in free flight, and the joint accelerations really are smaller than without it."""
+    arm = 0.05
+    cfg = _cfg(robot)
+    cfg.asset.armature = arm
+    env, cm, cfg = _make(robot, oracle_built, cfg=cfg)
+    ref, _, _ = _make(robot, oracle_built)
+    try:
+        rng = np.random.default_rng(5)
+        n, A = 8, cm["num_dofs"]
+        root, dof = _random_state(env, cm, rng, n)
+        ref.set("root_states", root)
+        ref.set("dof_state", dof)
+        tau = rng.uniform(-30, 30, (n, A)).astype(np.float32)
+        for e in (env, ref):
+            e.set("torques", tau)
+            e.call("simulate")
+        d1, d0 = env.get("dof_state"), ref.get("dof_state")
+        r1 = env.get("root_states")
+        dt = env.setup.sim_dt
+        g = np.array(cfg.sim.gravity, np.float64)
+        for i in range(n):
+            nud, _ = mass_matrix_dynamics(cm, root[i, :3].astype(np.float64), root[i, 3:7].astype(np.float64), dof[i, :, 0].astype(np.float64),
+                                          root[i, 7:10].astype(np.float64), root[i, 10:13].astype(np.float64), dof[i, :, 1].astype(np.float64),
+                                          tau[i].astype(np.float64), g, armature=arm)
+            scale = max(1.0, np.abs(nud).max())
+            np.testing.assert_allclose((d1[i, :, 1] - dof[i, :, 1]) / dt, nud[6:], atol=2e-3 * scale)
+            np.testing.assert_allclose((r1[i, 10:13] - root[i, 10:13]) / dt, nud[3:6], atol=2e-3 * scale)
+        acc1, acc0 = np.abs(d1[..., 1] - dof[..., 1]), np.abs(d0[..., 1] - dof[..., 1])
+        assert acc1.mean() < 0.8 * acc0.mean(), (acc1.mean(), acc0.mean())
+    finally:
+        env.close()
+        ref.close()
+
+
 def _momentum(cm, root, dof):
     Rb = _quat_mat(root[3:7].astype(np.float64))
     nu = np.concatenate([root[7:10], root[10:13], dof[:, 1]]).astype(np.float64)
@@ -207,6 +246,49 @@ def test_momentum_conserved_without_gravity(oracle_built):
             np.testing.assert_allclose(L1, P0[i][1], atol=0.05 * max(1.0, np.abs(P0[i][1]).max()))
     finally:
         env.close()
+
+
+def test_momentum_conserved_with_joints_at_their_velocity_limit(oracle_built):
+    """The regression test of round 4's solver fix (profiles/r04_diag_faults.txt).  Free flight, no gravity, the knee of every leg driven
+    by a constant 60 N m into its 20 rad/s velocity limit and held there for 40 substeps: internal torques cannot change the robot's
+    momentum.  With the limit as a row of the sweeps (a joint-space impulse, equal and opposite on child and parent; one active row per
+    chain is solved exactly) linear and angular momentum stay put and the base barely turns.  The clamp at integration it replaced took
+    the child's excess rate away and left the base its reaction: 0.3 N m s per joint and substep, i.e. a drift of tens of kg m^2 / s and
+    a base spin of several rad/s over the same 40 substeps.
+    With SEVERAL joints of one chain saturated at once the rows are relaxed Jacobi rows (1 / active rows, 4 iterations) and what they leave
+    goes to the integration clamp: the drift is smaller than before but not zero -- there only boundedness is asserted."""
+    for knees_only in (True, False):
+        env, cm, cfg = _make("anymal_c", oracle_built, n=4, gravity=False)
+        try:
+            rng = np.random.default_rng(2)
+            n, A = 4, 12
+            root, dof = _random_state(env, cm, rng, n)
+            root[:, 7:13] = 0.0
+            dof[..., 1] = 0.0
+            env.set("root_states", root)
+            env.set("dof_state", dof)
+            tau = (60.0 * rng.choice([-1.0, 1.0], (n, A))).astype(np.float32)
+            if knees_only:
+                tau[:, [0, 1, 3, 4, 6, 7, 9, 10]] = 0.0
+            env.set("torques", tau)
+            P0 = [_momentum(cm, root[i], dof[i]) for i in range(n)]
+            at_limit = 0
+            for k in range(40):
+                env.call("simulate")
+                at_limit = max(at_limit, int((np.abs(env.get("dof_state")[..., 1]) > 19.9).sum()))
+            r, d = env.get("root_states"), env.get("dof_state")
+            assert np.isfinite(r).all() and np.isfinite(d).all()
+            if knees_only:
+                assert at_limit == 16, at_limit                                   # all four knees of all four robots sit at the limit
+                assert np.abs(r[:, 10:13]).max() < 1.0, np.abs(r[:, 10:13]).max()  # the base barely turns
+                for i in range(n):
+                    P1, L1 = _momentum(cm, r[i], d[i])
+                    np.testing.assert_allclose(P1, P0[i][0], atol=0.5)                 # kg m / s (52 kg robot: < 1 cm / s)
+                    np.testing.assert_allclose(L1, P0[i][1], atol=2.5)                 # kg m^2 / s about the world origin, 5 m below the robot
+            else:
+                assert at_limit >= 24 and np.abs(r[:, 10:13]).max() < 40.0, (at_limit, np.abs(r[:, 10:13]).max())
+        finally:
+            env.close()
 
 
 @pytest.mark.parametrize("robot,height", [("anymal_c", 0.56), ("cassie", 0.95), ("a1", 0.36), ("anymal_b", 0.56)])
