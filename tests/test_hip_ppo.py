@@ -338,12 +338,15 @@ def test_split_bf16_gemm_is_fp32_accurate(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("M,rows,cols", [(24576, 256, 512), (4096, 128, 256), (3001, 72, 48), (1000, 512, 48), (640, 16, 128), (515, 264, 40)])
+@pytest.mark.parametrize("M,rows,cols", [(24576, 256, 512), (4096, 128, 256), (3001, 72, 48), (1000, 512, 48), (640, 16, 128), (515, 264, 40),
+                                         (3001, 128, 64), (1000, 256, 96), (129, 384, 32)])
 def test_weight_plane_gemms_are_fp32_accurate(mode, M, rows, cols):
     """The two GEMMs that take W [rows][cols] from its three bf16 planes -- forward A.W^T (planes as the reduction-contiguous
     operand) and input gradient A.W (the SAME planes read along their rows through ds_read_b64_tr_b16) -- against a float64
     product, beside the fp32-input MFMA kernel on the fp32 W: error <= 2 x that kernel's + 2^-22 max|C| (the planes are an
-    exact split).  Shapes: the update's big interior tiles, the rollout's 64x64 tiles, ragged rows / columns / k-tails."""
+    exact split).  Shapes: the update's big interior tiles, the rollout's 64x64 tiles, ragged rows / columns / k-tails; the last three
+    take the LDS-DMA forward (k_gemm_glds: K a multiple of 32, N of 128) with a ragged last row tile -- rows past M are clamped on the way in and
+    never stored."""
     import ctypes
     from legged_gym_dev_amd.lib import load
     lib = load()
