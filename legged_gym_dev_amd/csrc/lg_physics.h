@@ -157,22 +157,34 @@ __device__ __forceinline__ PhysCfg phys_cfg(const DevParams *__restrict__ P) {
 }
 
 struct Ground { float h; V3 n; };
+// The heightfield lookup in two halves, so that a caller with several points can have all their samples in flight before it needs the
+// first (lg_physics_pair.h: eight collision spheres per lane, eight round trips to the L2 one after the other otherwise).
+struct GroundTap { int16_t s00, s01, s10, s11; float tx, ty; };
 template <typename CFG>
-__device__ __forceinline__ Ground ground_at(const CFG &c, const int16_t *__restrict__ height_samples, float x, float y) {
-    if (c.terrain_type == 0) return {0.0f, {0.0f, 0.0f, 1.0f}};
+__device__ __forceinline__ GroundTap ground_fetch(const CFG &c, const int16_t *__restrict__ height_samples, float x, float y) {
+    if (c.terrain_type == 0) return {0, 0, 0, 0, 0.f, 0.f};
     float gx = (x + c.border_size) / c.hf_hscale, gy = (y + c.border_size) / c.hf_hscale;
     gx = fminf(fmaxf(gx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
     gy = fminf(fmaxf(gy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
     int ix = (int)gx, iy = (int)gy;
-    float tx = gx - ix, ty = gy - iy;
     const int16_t *hs = height_samples + (size_t)ix * c.hf_cols + iy;
-    float h00 = (float)hs[0] * c.hf_vscale, h01 = (float)hs[1] * c.hf_vscale;
-    float h10 = (float)hs[c.hf_cols] * c.hf_vscale, h11 = (float)hs[c.hf_cols + 1] * c.hf_vscale;
+    return {hs[0], hs[1], hs[c.hf_cols], hs[c.hf_cols + 1], gx - ix, gy - iy};
+}
+template <typename CFG>
+__device__ __forceinline__ Ground ground_finish(const CFG &c, const GroundTap &t) {
+    if (c.terrain_type == 0) return {0.0f, {0.0f, 0.0f, 1.0f}};
+    const float tx = t.tx, ty = t.ty;
+    float h00 = (float)t.s00 * c.hf_vscale, h01 = (float)t.s01 * c.hf_vscale;
+    float h10 = (float)t.s10 * c.hf_vscale, h11 = (float)t.s11 * c.hf_vscale;
     float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
     float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hf_hscale;
     float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hf_hscale;
     float inv = rsqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     return {h, {-dhdx * inv, -dhdy * inv, inv}};
+}
+template <typename CFG>
+__device__ __forceinline__ Ground ground_at(const CFG &c, const int16_t *__restrict__ height_samples, float x, float y) {
+    return ground_finish(c, ground_fetch(c, height_samples, x, y));
 }
 
 

@@ -143,7 +143,7 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
                                              const float *__restrict__ mat /* LDS: this env's restitution, compliance, thickness */,
                                              V3 *fslot, V3 &fbase, float *__restrict__ cst, float *__restrict__ lkp,
                                              float *__restrict__ lkh, const float *__restrict__ ltab, float *__restrict__ lmt,
-                                             SubProf &pr) {
+                                             SubProf &pr, bool want_forces = true /* wave-uniform: fslot / fbase are read by the caller */) {
     const float *__restrict__ lt = ltab + leg * LG_LT_STRIDE;
     const M3 Rb = quat_to_mat(root + 3);
     const V3 xw = {root[0], root[1], root[2]};
@@ -279,41 +279,51 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     // ---- contact detection + W per slot.  The records are shared by the pair: both lanes compute and store the same
     // values to the same column (each lane reads back what it wrote itself; no cross-lane ordering is relied on).
     const float mu = 0.5f * (friction + c.ground_friction);
-    unsigned amask = 0u;
+    unsigned amask = 0u, mym = 0u;                       // active slots of the pair; the ones THIS lane takes through the sweeps (alternating)
+    int ndealt = 0;
     const int nbase_it = (c.n_base_spheres + L - 1) / L;
-    for (int s = 0; s < nslots + nbase_it; ++s) {
-        const bool is_base = s >= nslots;
-        const int ub = s - nslots;
-        const int si = is_base ? LG_MAX_LEG_SLOTS + ub : s;
-        const bool exists = is_base ? (leg + ub * L < c.n_base_spheres) : true;
-        V3 cbk = {0.f, 0.f, 0.f}, Pc = {0.f, 0.f, 0.f}, nb = {0.f, 0.f, 1.f};
-        float rad = 0.f, vtarget = 0.f;
-        bool active = false;
-        if (exists) {
+    // Two passes over the slots, both written out (static records, wave-uniform guards): the first places every sphere in the world and
+    // fetches the heightfield samples under it, the second evaluates the gaps -- the samples of all slots are in flight together, and the
+    // slots' arithmetic interleaves.  Visiting order = ascending slot index, as the contact lists and their dealing assume.
+    V3 cbks[LG_NUM_SLOTS], cws[LG_NUM_SLOTS];
+    float rads[LG_NUM_SLOTS];
+    GroundTap taps[LG_NUM_SLOTS];
+#pragma unroll
+    for (int si = 0; si < LG_NUM_SLOTS; ++si) {
+        const bool is_base = si >= LG_MAX_LEG_SLOTS;
+        const int ub = si - LG_MAX_LEG_SLOTS;
+        if (is_base ? ub < nbase_it : si < nslots) {
             if (is_base) {
-                cbk = ld3(lt + LG_LT_BASE + 4 * ub);
-                rad = lt[LG_LT_BASE + 4 * ub + 3];
+                cbks[si] = ld3(lt + LG_LT_BASE + 4 * ub);
+                rads[si] = lt[LG_LT_BASE + 4 * ub + 3];
             } else {
-                cbk = {CF(s, 0), CF(s, 1), CF(s, 2)};              // from the kinematics pass
-                rad = lt[LG_LT_SLOTS + 4 * s + 3];
+                cbks[si] = {CF(si, 0), CF(si, 1), CF(si, 2)};          // from the kinematics pass
+                rads[si] = lt[LG_LT_SLOTS + 4 * si + 3];
             }
-            V3 cw = xw + mul(Rb, cbk);
-            Ground g = ground_at(c, c.height_samples, cw.x, cw.y);
-            float gap = (cw.z - g.h) * g.n.z - rad;
-            gap -= c.material_rand ? mat[2] : c.rest_offset;    // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
-            if (gap < c.contact_offset) {
-                active = true;
-                nb = mulT(Rb, g.n);
-                Pc = cbk - rad * nb;
-                vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
-            }
+            cws[si] = xw + mul(Rb, cbks[si]);
+            taps[si] = ground_fetch(c, c.height_samples, cws[si].x, cws[si].y);
         }
-        if (active) {                                   // records of inactive slots are never read for a result
-            CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
-            CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
-            CF(si, 12) = vtarget;
-            CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
-            amask |= 1u << si;
+    }
+#pragma unroll
+    for (int si = 0; si < LG_NUM_SLOTS; ++si) {
+        const bool is_base = si >= LG_MAX_LEG_SLOTS;
+        const int ub = si - LG_MAX_LEG_SLOTS;
+        if (is_base ? ub < nbase_it : si < nslots) {
+            const bool exists = is_base ? (leg + ub * L < c.n_base_spheres) : true;
+            const Ground g = ground_finish(c, taps[si]);
+            float gap = (cws[si].z - g.h) * g.n.z - rads[si];
+            gap -= c.material_rand ? mat[2] : c.rest_offset;    // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
+            if (exists && gap < c.contact_offset) {             // records of inactive slots are never read for a result
+                const V3 nb = mulT(Rb, g.n), Pc = cbks[si] - rads[si] * nb;
+                const float vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+                CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
+                CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
+                CF(si, 12) = vtarget;
+                CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
+                amask |= 1u << si;
+                if ((ndealt & 1) == (int)h) mym |= 1u << si;
+                ++ndealt;
+            }
         }
     }
     PSTAMP(pr, 6);
@@ -335,22 +345,23 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
 #endif
+            // joints outside the contact's chain (k > jl) drop out through a zero factor, not a branch: as `if (k <= jl) { ... }` the three test
+            // impulses compiled into 31 basic blocks (exec-mask regions), which the scheduler cannot interleave -- 2.7 k cycles per contact
             V3 pAi = -1.0f * sel3(h, dirs[a], cross(Pc, dirs[a]));
             float ui[J];
 #pragma unroll
             for (int k = J - 1; k >= 0; --k) {
-                if (k <= jl) {
-                    ui[k] = -pdot(S[k], pAi);
-                    pAi = pAi + (ui[k] * iD[k]) * U[k];
-                } else ui[k] = 0.f;
+                const float d = pdot(S[k], pAi);
+                ui[k] = k <= jl ? -d : 0.f;
+                pAi = pAi + (ui[k] * iD[k]) * U[k];
             }
             V3 dv = -1.0f * hmul(I0inv, pAi);
 #pragma unroll
-            for (int k = 0; k < J; ++k)
-                if (k <= jl) {
-                    float dq = (ui[k] - pdot(U[k], dv)) * iD[k];
-                    dv = dv + dq * S[k];
-                }
+            for (int k = 0; k < J; ++k) {
+                const float d = (ui[k] - pdot(U[k], dv)) * iD[k];
+                const float dq = k <= jl ? d : 0.f;
+                dv = dv + dq * S[k];
+            }
             const V3 part = sel3(h, dv, cross(dv, Pc));      // dv.v | dv.w x Pc
             const V3 dvP = part + px3(part);
 #pragma unroll
@@ -431,20 +442,28 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
             V3 fimp[J], fb = zero3;
 #pragma unroll
             for (int k = 0; k < J; ++k) fimp[k] = zero3;
-            for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
+            // The scalar contact law needs no spatial algebra, so the pair does not share it: each lane takes every other active contact of the
+            // (env, leg) (mym, dealt at detection) -- a leg with n contacts costs ceil(n / 2) trips, and a launch lasts as long as its workgroup
+            // with the most contacts per leg (profiles/r04_substeps_spread.txt: fallen robots, 3-8 contacts per leg, set the launch's duration).
+            // Per trip the lanes swap what the other needs: the partner's half of the velocity of the link MY contact sits on, and the partner's half of
+            // the impulse I found.  DPP moves run outside the divergent part (they would read disabled partners inside it).
+            for (unsigned rem = mym; __any(rem != 0u); rem &= rem - 1u) {
                 const bool active = rem != 0u;
                 const int si = active ? __ffs(rem) - 1 : 0;
                 const bool is_base = si >= LG_MAX_LEG_SLOTS;
                 const int jl = is_base ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
-                V3 vl = velf0;
+                const int jlp = __builtin_amdgcn_update_dpp(0, jl, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);     // the link of the partner's contact
+                V3 vm = velf0, vq = velf0;                      // my half of my contact's link, and of the partner's
 #pragma unroll
-                for (int k = 0; k < J; ++k)
-                    if (jl == k) vl = velf[k];
-                // the point velocity needs both halves: executed by every lane (DPP under a divergent branch would read
-                // disabled partners), the contact law below only where this pair still has a contact to visit
+                for (int k = 0; k < J; ++k) {
+                    if (jl == k) vm = velf[k];
+                    if (jlp == k) vq = velf[k];
+                }
+                const V3 vo = px3(vq);                          // the partner's half of MY contact's link
+                const V3 wl = sel3(h, vo, vm), vlin = sel3(h, vm, vo);
                 const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
-                const V3 part = sel3(h, vl, cross(vl, Pc));
-                const V3 vP = part + px3(part);
+                const V3 vP = vlin + cross(wl, Pc);
+                V3 fmine = zero3, fsend = zero3;                // my half of the impulse of my contact, and the partner's half of it
                 if (active) {
                     const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
                     const V3 t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}, t2 = cross(nb, t1);
@@ -460,13 +479,19 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
                     float l2 = ol2 - relax * vc2 * CF(si, 11);
                     float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
                     if (mag > lim) { float sc = lim * frcp(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
-                    V3 dl = (ln - oln) * nb + (l1 - ol1) * t1 + (l2 - ol2) * t2;
+                    const V3 dl = (ln - oln) * nb + (l1 - ol1) * t1 + (l2 - ol2) * t2;
                     CF(si, 13) = ln; CF(si, 14) = l1; CF(si, 15) = l2;
-                    const V3 f = sel3(h, dl, cross(Pc, dl));
-                    if (is_base) fb = fb + f;
+                    const V3 tq = cross(Pc, dl);
+                    fmine = sel3(h, dl, tq);
+                    fsend = sel3(h, tq, dl);
+                }
+                const V3 fget = px3(fsend);                     // my half of the partner's contact's impulse (zero if it had none this trip)
+                if (is_base) fb = fb + fmine;
+                if (jlp < 0) fb = fb + fget;
 #pragma unroll
-                    for (int k = 0; k < J; ++k)
-                        if (jl == k) fimp[k] = fimp[k] + f;
+                for (int k = 0; k < J; ++k) {
+                    if (jl == k) fimp[k] = fimp[k] + fmine;
+                    if (jlp == k) fimp[k] = fimp[k] + fget;
                 }
             }
             float ui[J], timp[J];
@@ -506,7 +531,7 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
 #pragma unroll
     for (int si = 0; si < LG_NUM_SLOTS; ++si) {
         V3 f = {0.f, 0.f, 0.f};
-        if ((amask >> si) & 1u) {
+        if (want_forces && ((amask >> si) & 1u)) {
             const V3 nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
             const V3 t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}, t2 = cross(nb, t1);
             f = inv_dt * mul(Rb, CF(si, 13) * nb + CF(si, 14) * t1 + CF(si, 15) * t2);
