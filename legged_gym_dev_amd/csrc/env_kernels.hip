@@ -19,47 +19,50 @@ __global__ void k_set_actions(const DevParams *__restrict__ P, const float *__re
 // Actuator net, wide form: 8 lanes per (env, joint) row, lane k owns hidden unit k of both LSTM layers.  The 113 weights
 // lane k needs are staged once per block into one 16-byte aligned LDS record per k (stride 116 floats: the eight records'
 // b128 reads fall on disjoint banks) and read into VGPRs once per substep for all rows of the thread.  The 8 hidden values
-// of a row are exchanged with DPP only (quad broadcast + the xor-4 swap of lg_physics_pair.h), no LDS round trip: lane k
-// receives unit (k&4)+q from its own quad and unit ((k&4)^4)+q from the other and multiplies each by the matching weight,
-// so the lower and upper quads add the eight products in a different order.  All NR rows of a thread advance stage by
-// stage, which gives the scheduler NR independent chains to hide the exp / rcp latencies with.
+// of a row are exchanged with DPP only (quad rotations + row_half_mirror, lstm_acc below), no LDS round trip; the image stores each
+// lane's weights in the order the lane meets the units, so the eight lanes add their eight products in eight different orders.
+// All NR rows of a thread advance stage by stage, which gives the scheduler NR independent chains to hide the exp / rcp latencies with.
 __device__ __forceinline__ float fsigm(float x) { return frcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * frcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
 template <int Q>
 __device__ __forceinline__ float quad_bcast(float x) {                   // lane (i & ~3) + Q of every quad
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), Q * 0x55, 0xF, 0xF, true));
 }
-// g[r][gate] += sum_q W[gate][q] h_r[q] over the 8 units of the row; wo / wx = this lane's weights for the units of its own /
-// the other quad, [gate][q]
-template <int Q, int NR>
-__device__ __forceinline__ void lstm_acc_q(float (&g)[NR][4], const float (&h)[NR], const float (&wo)[4][4], const float (&wx)[4][4]) {
+// g[r][gate] += sum_u W[gate][u] h_r[u] over the 8 units of the row.  The row's hidden values are rotated inside their quads (r = 0..3:
+// lane j then holds unit (j & 4) + ((j + r) & 3)); lane k multiplies what it holds itself and what lane 7 - k holds (row_half_mirror, a DPP
+// operand of the multiply-add: no instruction of its own) by the two weight quadruples the image stores for (k, r) -- 3 moves and 32
+// multiply-adds per row and matrix (round 3: quad broadcasts and a two-move swap per unit, 56 instructions).
+template <int R>
+__device__ __forceinline__ float quad_rot(float x) {                     // lane j <- lane (j & ~3) + ((j + R) & 3)
+    constexpr int ctl = ((0 + R) & 3) | (((1 + R) & 3) << 2) | (((2 + R) & 3) << 4) | (((3 + R) & 3) << 6);
+    return R == 0 ? x : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctl, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_mirror(float x) {                  // lane j <- lane 7 - j of its group of eight
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+}
+template <int R, int NR>
+__device__ __forceinline__ void lstm_acc_r(float (&g)[NR][4], const float (&h)[NR], const float *__restrict__ wm) {
+    const float4 wo = *reinterpret_cast<const float4 *>(wm + R * 8), wx = *reinterpret_cast<const float4 *>(wm + R * 8 + 4);
+    const float wov[4] = {wo.x, wo.y, wo.z, wo.w}, wxv[4] = {wx.x, wx.y, wx.z, wx.w};
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const float b = quad_bcast<Q>(h[r]), x4 = lane_xor4(b);
+        const float t = quad_rot<R>(h[r]), x = half_mirror(t);
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) g[r][gt] += wo[gt][Q] * b + wx[gt][Q] * x4;
+        for (int gt = 0; gt < 4; ++gt) g[r][gt] = fmaf(wxv[gt], x, fmaf(wov[gt], t, g[r][gt]));
     }
 }
 template <int NR>
-__device__ __forceinline__ void lstm_acc(float (&g)[NR][4], const float (&h)[NR], const float *__restrict__ wm, int own4) {
-    float wo[4][4], wx[4][4];
-#pragma unroll
-    for (int gt = 0; gt < 4; ++gt) {
-        const float4 a = *reinterpret_cast<const float4 *>(wm + gt * 8 + own4), b = *reinterpret_cast<const float4 *>(wm + gt * 8 + (own4 ^ 4));
-        wo[gt][0] = a.x; wo[gt][1] = a.y; wo[gt][2] = a.z; wo[gt][3] = a.w;
-        wx[gt][0] = b.x; wx[gt][1] = b.y; wx[gt][2] = b.z; wx[gt][3] = b.w;
-    }
-    lstm_acc_q<0, NR>(g, h, wo, wx);
-    lstm_acc_q<1, NR>(g, h, wo, wx);
-    lstm_acc_q<2, NR>(g, h, wo, wx);
-    lstm_acc_q<3, NR>(g, h, wo, wx);
+__device__ __forceinline__ void lstm_acc(float (&g)[NR][4], const float (&h)[NR], const float *__restrict__ wm) {
+    lstm_acc_r<0, NR>(g, h, wm);
+    lstm_acc_r<1, NR>(g, h, wm);
+    lstm_acc_r<2, NR>(g, h, wm);
+    lstm_acc_r<3, NR>(g, h, wm);
 }
 // One actuator-net update of the NR rows of this thread (lane k = hidden unit k of both layers); wr = the LDS record of k.
 // y[r] = the row's output sum, in every lane of the row.
 template <int NR>
 __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, const float (&x0)[NR], const float (&x1)[NR], float (&h0)[NR],
                                            float (&c0)[NR], float (&h1)[NR], float (&c1)[NR], float (&y)[NR]) {
-    const int own4 = k & 4;
     const float4 b0 = *reinterpret_cast<const float4 *>(wr), b1 = *reinterpret_cast<const float4 *>(wr + 4);
     const float4 wa = *reinterpret_cast<const float4 *>(wr + 8), wb = *reinterpret_cast<const float4 *>(wr + 12);
     const float bias0[4] = {b0.x, b0.y, b0.z, b0.w}, bias1[4] = {b1.x, b1.y, b1.z, b1.w};
@@ -69,7 +72,7 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) g[r][gt] = bias0[gt] + wi[gt][0] * x0[r] + wi[gt][1] * x1[r];
-    lstm_acc<NR>(g, h0, wr + 16, own4);
+    lstm_acc<NR>(g, h0, wr + 16);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         c0[r] = fsigm(g[r][1]) * c0[r] + fsigm(g[r][0]) * ftanh(g[r][2]);
@@ -79,8 +82,8 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) g[r][gt] = bias1[gt];
-    lstm_acc<NR>(g, h0, wr + 48, own4);
-    lstm_acc<NR>(g, h1, wr + 80, own4);
+    lstm_acc<NR>(g, h0, wr + 48);
+    lstm_acc<NR>(g, h1, wr + 80);
     const float lw = wr[112];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {

@@ -37,9 +37,14 @@ static inline float lstm_lds_image(const float *__restrict__ w, int o) {
     if (f < 4) return w[BIH0 + f * 8 + k] + w[BHH0 + f * 8 + k];
     if (f < 8) return w[BIH1 + (f - 4) * 8 + k] + w[BHH1 + (f - 4) * 8 + k];
     if (f < 16) return w[WIH0 + (((f - 8) >> 1) * 8 + k) * 2 + ((f - 8) & 1)];
-    if (f < 48) return w[WHH0 + (((f - 16) >> 3) * 8 + k) * 8 + ((f - 16) & 7)];
-    if (f < 80) return w[WIH1 + (((f - 48) >> 3) * 8 + k) * 8 + ((f - 48) & 7)];
-    if (f < 112) return w[WHH1 + (((f - 80) >> 3) * 8 + k) * 8 + ((f - 80) & 7)];
+    if (f < 112) {
+        // the three 32 x 8 matrices in the order lane k CONSUMES them (env_kernels.hip lstm_acc): for rotation r = 0..3 of the row's hidden
+        // values inside their quad, four gate weights for the unit that lands on lane k itself and four for the unit that lands on lane 7 - k
+        const int m = (f - 16) >> 5, e = (f - 16) & 31, r = e >> 3, other = (e >> 2) & 1, gt = e & 3;
+        const int src = other ? 7 - k : k, unit = (src & 4) + ((src + r) & 3);
+        const int base = m == 0 ? WHH0 : m == 1 ? WIH1 : WHH1;
+        return w[base + (gt * 8 + k) * 8 + unit];
+    }
     return f == 112 ? w[LW + k] : 0.0f;
 }
 
