@@ -335,38 +335,36 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
         V3 t1, t2;
         tangents(nb, t1, t2);
         V3 dirs[3] = {nb, t1, t2};
-        float Wc[3][3];
-#ifdef LG_EXP_W_DIRS                  // timing experiment only (make prof PROFFLAGS=-DLG_EXP_W_DIRS=1; wrong contact law): what the launch costs when
-        for (int a = 0; a < 3; ++a)   // the W phase computes 1 of its 3 test impulses -- the most a four-lane split of that phase could save
-            for (int b = 0; b < 3; ++b) Wc[b][a] = a == b ? 1.0f : 0.0f;
-#pragma unroll
-        for (int a = 0; a < LG_EXP_W_DIRS; ++a) {
-#else
+        // W = G^T Phi G (G = the three unit impulses at the contact, Phi = the chain's response at the link) from the INWARD pass alone:
+        // with the innovations u_a[k] = -S_k . p_a,k and the force p_a,0 that reaches the base, the articulated-body factorisation
+        // M^-1 = (I - H psi K)^T D^-1 (I - H psi K) gives  W_ab = sum_k u_a[k] u_b[k] / D_k + p_a,0 . I0^-1 p_b,0  -- no outward pass, no
+        // point-velocity reconstruction (a third fewer instructions than propagating each impulse out again; the one-lane map and the
+        // oracle keep the literal form, and the parity tests compare the two).  Joints outside the contact's chain (k > jl) drop out
+        // through a zero factor, not a branch: as `if (k <= jl) { ... }` the three impulses compiled into 31 basic blocks (exec-mask
+        // regions) that the scheduler could not interleave.
+        float Wc[3][3], uu[3][J];
+        V3 p0[3], y0[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-#endif
-            // joints outside the contact's chain (k > jl) drop out through a zero factor, not a branch: as `if (k <= jl) { ... }` the three test
-            // impulses compiled into 31 basic blocks (exec-mask regions), which the scheduler cannot interleave -- 2.7 k cycles per contact
-            V3 pAi = -1.0f * sel3(h, dirs[a], cross(Pc, dirs[a]));
-            float ui[J];
+            V3 pAi = sel3(h, dirs[a], cross(Pc, dirs[a]));
 #pragma unroll
             for (int k = J - 1; k >= 0; --k) {
                 const float d = pdot(S[k], pAi);
-                ui[k] = k <= jl ? -d : 0.f;
-                pAi = pAi + (ui[k] * iD[k]) * U[k];
+                uu[a][k] = k <= jl ? d : 0.f;
+                pAi = pAi - (uu[a][k] * iD[k]) * U[k];
             }
-            V3 dv = -1.0f * hmul(I0inv, pAi);
-#pragma unroll
-            for (int k = 0; k < J; ++k) {
-                const float d = (ui[k] - pdot(U[k], dv)) * iD[k];
-                const float dq = k <= jl ? d : 0.f;
-                dv = dv + dq * S[k];
-            }
-            const V3 part = sel3(h, dv, cross(dv, Pc));      // dv.v | dv.w x Pc
-            const V3 dvP = part + px3(part);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) Wc[b][a] = dot(dirs[b], dvP);
+            p0[a] = pAi;
+            y0[a] = hmul(I0inv, pAi);
         }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) {
+                float w = dot(p0[b], y0[a]);                     // my half; the pair's sum below
+#pragma unroll
+                for (int k = 0; k < J; ++k) w += 0.5f * (uu[a][k] * iD[k]) * uu[b][k];      // identical in both lanes: half each
+                Wc[b][a] = psum(w);
+            }
         if (valid) {
             CF(si, 16) = t1.x; CF(si, 17) = t1.y; CF(si, 18) = t1.z;   // first tangent: the sweeps and the force output rebuild t2 = n x t1 only
             if (c.material_rand) Wc[0][0] += mat[1] * inv_dt * inv_dt;      // compliance (m/N) as constraint-force mixing on the normal row
