@@ -129,7 +129,7 @@ struct PhysCfg {
     float gravity[3];
     float max_depenetration_velocity, contact_erp, ground_restitution, ground_friction, contact_offset, bounce_threshold;
     float max_linear_velocity, max_angular_velocity, armature, rest_offset;
-    float border_size, hf_hscale, hf_vscale;
+    float border_size, hf_hscale, hf_vscale, hf_inv_hscale;
     int hf_rows, hf_cols, terrain_type, solver_iterations, material_rand;
     int n_leg_slots, n_base_spheres;
     unsigned long long slot_link_pk;
@@ -146,6 +146,7 @@ __device__ __forceinline__ PhysCfg phys_cfg(const DevParams *__restrict__ P) {
     k.max_linear_velocity = c.max_linear_velocity; k.max_angular_velocity = c.max_angular_velocity;
     k.armature = c.armature; k.rest_offset = c.rest_offset;
     k.border_size = c.border_size; k.hf_hscale = c.hf_hscale; k.hf_vscale = c.hf_vscale;
+    k.hf_inv_hscale = 1.0f / c.hf_hscale;
     k.hf_rows = c.hf_rows; k.hf_cols = c.hf_cols; k.terrain_type = c.terrain_type;
     k.solver_iterations = c.solver_iterations; k.material_rand = c.material_rand;
     k.n_leg_slots = P->n_leg_slots; k.n_base_spheres = P->n_base_spheres; k.slot_link_pk = P->slot_link_pk;
@@ -163,7 +164,8 @@ struct GroundTap { int16_t s00, s01, s10, s11; float tx, ty; };
 template <typename CFG>
 __device__ __forceinline__ GroundTap ground_fetch(const CFG &c, const int16_t *__restrict__ height_samples, float x, float y) {
     if (c.terrain_type == 0) return {0, 0, 0, 0, 0.f, 0.f};
-    float gx = (x + c.border_size) / c.hf_hscale, gy = (y + c.border_size) / c.hf_hscale;
+    const float inv_h = 1.0f / c.hf_hscale;          // products with the reciprocal pitch: the definition all three implementations share
+    float gx = (x + c.border_size) * inv_h, gy = (y + c.border_size) * inv_h;
     gx = fminf(fmaxf(gx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
     gy = fminf(fmaxf(gy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
     int ix = (int)gx, iy = (int)gy;
@@ -177,14 +179,37 @@ __device__ __forceinline__ Ground ground_finish(const CFG &c, const GroundTap &t
     float h00 = (float)t.s00 * c.hf_vscale, h01 = (float)t.s01 * c.hf_vscale;
     float h10 = (float)t.s10 * c.hf_vscale, h11 = (float)t.s11 * c.hf_vscale;
     float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
-    float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hf_hscale;
-    float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hf_hscale;
+    const float inv_h = 1.0f / c.hf_hscale;
+    float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) * inv_h;
+    float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) * inv_h;
     float inv = rsqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
     return {h, {-dhdx * inv, -dhdy * inv, inv}};
 }
 template <typename CFG>
 __device__ __forceinline__ Ground ground_at(const CFG &c, const int16_t *__restrict__ height_samples, float x, float y) {
     return ground_finish(c, ground_fetch(c, height_samples, x, y));
+}
+// The control loop's own pair (PhysCfg: launch constants in registers): the four divisions by the grid pitch per point are products with
+// its reciprocal (32 IEEE divisions per lane and substep otherwise, a third of the detection's instructions; the one-lane map and the oracle define the lookup the same way).
+__device__ __forceinline__ GroundTap ground_fetch(const PhysCfg &c, const int16_t *__restrict__ height_samples, float x, float y) {
+    if (c.terrain_type == 0) return {0, 0, 0, 0, 0.f, 0.f};
+    float gx = (x + c.border_size) * c.hf_inv_hscale, gy = (y + c.border_size) * c.hf_inv_hscale;
+    gx = fminf(fmaxf(gx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
+    gy = fminf(fmaxf(gy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
+    int ix = (int)gx, iy = (int)gy;
+    const int16_t *hs = height_samples + (size_t)ix * c.hf_cols + iy;
+    return {hs[0], hs[1], hs[c.hf_cols], hs[c.hf_cols + 1], gx - ix, gy - iy};
+}
+__device__ __forceinline__ Ground ground_finish(const PhysCfg &c, const GroundTap &t) {
+    if (c.terrain_type == 0) return {0.0f, {0.0f, 0.0f, 1.0f}};
+    const float tx = t.tx, ty = t.ty;
+    float h00 = (float)t.s00 * c.hf_vscale, h01 = (float)t.s01 * c.hf_vscale;
+    float h10 = (float)t.s10 * c.hf_vscale, h11 = (float)t.s11 * c.hf_vscale;
+    float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
+    float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) * c.hf_inv_hscale;
+    float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) * c.hf_inv_hscale;
+    float inv = rsqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+    return {h, {-dhdx * inv, -dhdy * inv, inv}};
 }
 
 

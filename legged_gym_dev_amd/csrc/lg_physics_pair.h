@@ -385,50 +385,56 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     // base spins of hundreds of rad/s under actions of +-20 and more, what round 3's fault guard was resetting).
 #define LM(j, f) lmt[((j) * 4 + (f)) * 64 + pcol]
     unsigned lmask = 0u;
+    float lsgn[J], lvt[J];
+    float jlo[J], jhi[J], jvl[J];                       // the joints' limits, read once per call (also used by the integration below)
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31], vlim = lt[LG_LT_JOINT * j + 29];
-        float sgn = 0.f, gap = 0.f;
-        if (hi > lo) {
-            const float qn = q[j] + dt * qdf[j];
-            if (qn > hi) { sgn = 1.0f; gap = hi - q[j]; }
-            else if (qn < lo) { sgn = -1.0f; gap = q[j] - lo; }
-        }
+    for (int j = 0; j < J; ++j) { jlo[j] = lt[LG_LT_JOINT * j + 30]; jhi[j] = lt[LG_LT_JOINT * j + 31]; jvl[j] = lt[LG_LT_JOINT * j + 29]; }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {                       // which rows exist: all joints first, so that the common case (none) is one test
+        const float lo = jlo[j], hi = jhi[j], vlim = jvl[j];
+        // selects, not branches: as nested ifs the three joints' tests compiled into 36 exec-mask regions (1.4 k cycles per substep with no limit in play)
+        const float qn = q[j] + dt * qdf[j];
+        const bool haslim = hi > lo, up = haslim && qn > hi, dn = haslim && !up && qn < lo;
+        float sgn = up ? 1.0f : dn ? -1.0f : 0.f;
+        const float gap = up ? hi - q[j] : dn ? q[j] - lo : 0.f;
         // the outward rate the row allows: stop exactly at the position limit (or come back from beyond it), and never above the velocity limit
         float vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
-        if (vlim > 0.0f) {
-            if (sgn == 0.f) {
-                if (qdf[j] > vlim) { sgn = 1.0f; vtarget = -vlim; }
-                else if (qdf[j] < -vlim) { sgn = -1.0f; vtarget = -vlim; }
-            } else vtarget = fmaxf(vtarget, -vlim);
-        }
-        const bool act = sgn != 0.f;
-        if (!__any(act)) continue;
-        V3 pAi = zero3;
-        float ui[J];
+        const bool hasv = vlim > 0.0f, free = sgn == 0.f, vup = hasv && free && qdf[j] > vlim, vdn = hasv && free && qdf[j] < -vlim;
+        vtarget = (vup || vdn) ? -vlim : (hasv && !free) ? fmaxf(vtarget, -vlim) : vtarget;
+        sgn = vup ? 1.0f : vdn ? -1.0f : sgn;
+        lsgn[j] = sgn; lvt[j] = vtarget;
+        if (sgn != 0.f) lmask |= 1u << j;
+    }
+    if (__any(lmask != 0u)) {
 #pragma unroll
-        for (int k = J - 1; k >= 0; --k) {
-            if (k > j) ui[k] = 0.f;
-            else {
-                ui[k] = (k == j ? 1.0f : 0.f) - pdot(S[k], pAi);
-                pAi = pAi + (ui[k] * iD[k]) * U[k];
-            }
-        }
-        V3 dv = -1.0f * hmul(I0inv, pAi);
-        float Wj = 0.f;
+        for (int j = 0; j < J; ++j) {
+            const bool act = (lmask >> j) & 1u;
+            if (!__any(act)) continue;
+            V3 pAi = zero3;
+            float ui[J];
 #pragma unroll
-        for (int k = 0; k < J; ++k)
-            if (k <= j) {
-                const float dq = (ui[k] - pdot(U[k], dv)) * iD[k];
-                dv = dv + dq * S[k];
-                if (k == j) Wj = dq;
+            for (int k = J - 1; k >= 0; --k) {
+                if (k > j) ui[k] = 0.f;
+                else {
+                    ui[k] = (k == j ? 1.0f : 0.f) - pdot(S[k], pAi);
+                    pAi = pAi + (ui[k] * iD[k]) * U[k];
+                }
             }
-        if (act) {
-            lmask |= 1u << j;
-            LM(j, 0) = sgn;
-            LM(j, 1) = vtarget;
-            LM(j, 2) = Wj > 1e-9f ? frcp(Wj) : 0.f;
-            LM(j, 3) = 0.f;
+            V3 dv = -1.0f * hmul(I0inv, pAi);
+            float Wj = 0.f;
+#pragma unroll
+            for (int k = 0; k < J; ++k)
+                if (k <= j) {
+                    const float dq = (ui[k] - pdot(U[k], dv)) * iD[k];
+                    dv = dv + dq * S[k];
+                    if (k == j) Wj = dq;
+                }
+            if (act) {
+                LM(j, 0) = lsgn[j];
+                LM(j, 1) = lvt[j];
+                LM(j, 2) = Wj > 1e-9f ? frcp(Wj) : 0.f;
+                LM(j, 3) = 0.f;
+            }
         }
     }
     const float rlim = frcp((float)max(__popc(lmask), 1));
@@ -561,13 +567,13 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     for (int j = 0; j < J; ++j) {
         float v = qdf[j];
         {
-            const float lo = lt[LG_LT_JOINT * j + 30], hi = lt[LG_LT_JOINT * j + 31];
+            const float lo = jlo[j], hi = jhi[j];
             if (hi > lo) {
                 const float qn = fminf(fmaxf(q[j] + dt * v, fminf(lo, q[j])), fmaxf(hi, q[j]));
                 v = (qn - q[j]) * inv_dt;
             }
         }
-        float vl = lt[LG_LT_JOINT * j + 29];
+        const float vl = jvl[j];
         if (vl > 0.0f) v = fminf(fmaxf(v, -vl), vl);
         qd[j] = v;
         q[j] += dt * v;
@@ -585,9 +591,20 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     root[7] = vw.x; root[8] = vw.y; root[9] = vw.z;
     root[10] = ww.x; root[11] = ww.y; root[12] = ww.z;
     float ang = sqrtf(dot(wn, wn)) * dt;
-    float sh, ch = cosf(0.5f * ang);
+    float sh, ch;
     V3 ax;
-    if (ang > 1e-8f) { sh = sinf(0.5f * ang); ax = (dt / ang) * wn; } else { sh = 0.5f * dt; ax = wn; }
+    if (__all(ang < 0.5f)) {                            // every robot of the wave turns less than half a radian this substep (28 deg: 100 rad/s
+        // at the 200 Hz physics): sin and cos of the half angle from their series, truncation below 1e-12 -- the library calls carry an
+        // argument reduction for any angle that costs ~400 cycles of every substep
+        const float a = 0.5f * ang, a2 = a * a;
+        ch = 1.0f + a2 * (-0.5f + a2 * (4.16666667e-2f + a2 * (-1.38888889e-3f + a2 * 2.48015873e-5f)));
+        const float sinc = 1.0f + a2 * (-1.66666667e-1f + a2 * (8.33333333e-3f + a2 * (-1.98412698e-4f + a2 * 2.75573192e-6f)));
+        sh = 0.5f * dt * sinc;                          // sin(a) / |wn|: the axis below stays unnormalised
+        ax = wn;
+    } else {
+        ch = cosf(0.5f * ang);
+        if (ang > 1e-8f) { sh = sinf(0.5f * ang); ax = (dt / ang) * wn; } else { sh = 0.5f * dt; ax = wn; }
+    }
     float dq[4] = {sh * ax.x, sh * ax.y, sh * ax.z, ch};
     float *qq = root + 3;
     float qn[4] = {qq[3] * dq[0] + qq[0] * dq[3] + qq[1] * dq[2] - qq[2] * dq[1],

@@ -116,7 +116,8 @@ struct Ground { float h; V3 n; };
 static Ground ground_at(const Env &e, float x, float y) {
     const lg_cfg &c = e.cfg;
     if (c.terrain_type == 0) return {0.0f, {0.0f, 0.0f, 1.0f}};
-    float gx = (x + c.border_size) / c.hf_hscale, gy = (y + c.border_size) / c.hf_hscale;
+    const float inv_h = 1.0f / c.hf_hscale;      // grid coordinates and slopes as products with the reciprocal pitch (what the HIP path computes)
+    float gx = (x + c.border_size) * inv_h, gy = (y + c.border_size) * inv_h;
     gx = std::min(std::max(gx, 0.0f), (float)(c.hf_rows - 1) - 1e-3f);
     gy = std::min(std::max(gy, 0.0f), (float)(c.hf_cols - 1) - 1e-3f);
     int ix = (int)gx, iy = (int)gy;
@@ -124,8 +125,8 @@ static Ground ground_at(const Env &e, float x, float y) {
     auto H = [&](int a, int b) { return (float)e.height_samples[(size_t)a * c.hf_cols + b] * c.hf_vscale; };
     float h00 = H(ix, iy), h10 = H(ix + 1, iy), h01 = H(ix, iy + 1), h11 = H(ix + 1, iy + 1);
     float h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
-    float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / c.hf_hscale;
-    float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / c.hf_hscale;
+    float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) * inv_h;
+    float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) * inv_h;
     float inv = 1.0f / std::sqrt(dhdx * dhdx + dhdy * dhdy + 1.0f);
     return {h, {-dhdx * inv, -dhdy * inv, inv}};
 }
