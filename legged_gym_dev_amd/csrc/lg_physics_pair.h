@@ -279,53 +279,54 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     // ---- contact detection + W per slot.  The records are shared by the pair: both lanes compute and store the same
     // values to the same column (each lane reads back what it wrote itself; no cross-lane ordering is relied on).
     const float mu = 0.5f * (friction + c.ground_friction);
-    unsigned amask = 0u, mym = 0u;                       // active slots of the pair; the ones THIS lane takes through the sweeps (alternating)
-    int ndealt = 0;
+    // Detection is scalar work per sphere, so the pair does not share it either: lane h takes slots 2i + h (the table rows of the leg's
+    // spheres and of the base spheres dealt to this leg are contiguous, LG_LT_SLOTS + 4 si), two passes, both written out -- the first
+    // places the spheres in the world and fetches the heightfield samples under them (all in flight together), the second evaluates the
+    // gaps and writes the records of the slots in contact to the pair's shared column.  Half the instructions of every lane visiting
+    // all eight slots (round 4, until here: 10 k of the launch's 150 k cycles).
+    static_assert(LG_NUM_SLOTS % 2 == 0, "slots are dealt to the two lanes of a pair");
     const int nbase_it = (c.n_base_spheres + L - 1) / L;
-    // Two passes over the slots, both written out (static records, wave-uniform guards): the first places every sphere in the world and
-    // fetches the heightfield samples under it, the second evaluates the gaps -- the samples of all slots are in flight together, and the
-    // slots' arithmetic interleaves.  Visiting order = ascending slot index, as the contact lists and their dealing assume.
-    V3 cbks[LG_NUM_SLOTS], cws[LG_NUM_SLOTS];
-    float rads[LG_NUM_SLOTS];
-    GroundTap taps[LG_NUM_SLOTS];
+    V3 cbks[LG_NUM_SLOTS / 2], cws[LG_NUM_SLOTS / 2];
+    float rads[LG_NUM_SLOTS / 2];
+    GroundTap taps[LG_NUM_SLOTS / 2];
 #pragma unroll
-    for (int si = 0; si < LG_NUM_SLOTS; ++si) {
+    for (int i = 0; i < LG_NUM_SLOTS / 2; ++i) {
+        const int si = 2 * i + (int)h;
+        const bool is_base = si >= LG_MAX_LEG_SLOTS;
+        const float *tb = lt + LG_LT_SLOTS + 4 * si;
+        const float *cp = is_base ? tb : &CF(si, 0);            // base spheres: the table's centre; leg spheres: from the kinematics pass
+        const int cs = is_base ? 1 : 64;
+        cbks[i] = {cp[0], cp[cs], cp[2 * cs]};
+        rads[i] = tb[3];
+        cws[i] = xw + mul(Rb, cbks[i]);
+        taps[i] = ground_fetch(c, c.height_samples, cws[i].x, cws[i].y);
+    }
+    unsigned amine = 0u;
+#pragma unroll
+    for (int i = 0; i < LG_NUM_SLOTS / 2; ++i) {
+        const int si = 2 * i + (int)h;
         const bool is_base = si >= LG_MAX_LEG_SLOTS;
         const int ub = si - LG_MAX_LEG_SLOTS;
-        if (is_base ? ub < nbase_it : si < nslots) {
-            if (is_base) {
-                cbks[si] = ld3(lt + LG_LT_BASE + 4 * ub);
-                rads[si] = lt[LG_LT_BASE + 4 * ub + 3];
-            } else {
-                cbks[si] = {CF(si, 0), CF(si, 1), CF(si, 2)};          // from the kinematics pass
-                rads[si] = lt[LG_LT_SLOTS + 4 * si + 3];
-            }
-            cws[si] = xw + mul(Rb, cbks[si]);
-            taps[si] = ground_fetch(c, c.height_samples, cws[si].x, cws[si].y);
+        const bool exists = is_base ? (ub < nbase_it && leg + ub * L < c.n_base_spheres) : si < nslots;
+        const Ground g = ground_finish(c, taps[i]);
+        float gap = (cws[i].z - g.h) * g.n.z - rads[i];
+        gap -= c.material_rand ? mat[2] : c.rest_offset;    // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
+        if (exists && gap < c.contact_offset) {             // records of inactive slots are never read for a result
+            const V3 nb = mulT(Rb, g.n), Pc = cbks[i] - rads[i] * nb;
+            const float vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
+            CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
+            CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
+            CF(si, 12) = vtarget;
+            CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
+            amine |= 1u << si;
         }
     }
-#pragma unroll
-    for (int si = 0; si < LG_NUM_SLOTS; ++si) {
-        const bool is_base = si >= LG_MAX_LEG_SLOTS;
-        const int ub = si - LG_MAX_LEG_SLOTS;
-        if (is_base ? ub < nbase_it : si < nslots) {
-            const bool exists = is_base ? (leg + ub * L < c.n_base_spheres) : true;
-            const Ground g = ground_finish(c, taps[si]);
-            float gap = (cws[si].z - g.h) * g.n.z - rads[si];
-            gap -= c.material_rand ? mat[2] : c.rest_offset;    // shape thickness (asset option, or the env's draw): the robot rests that far off the surface
-            if (exists && gap < c.contact_offset) {             // records of inactive slots are never read for a result
-                const V3 nb = mulT(Rb, g.n), Pc = cbks[si] - rads[si] * nb;
-                const float vtarget = gap >= 0.0f ? -gap * inv_dt : fminf(-gap * c.contact_erp * inv_dt, c.max_depenetration_velocity);
-                CF(si, 0) = Pc.x; CF(si, 1) = Pc.y; CF(si, 2) = Pc.z;
-                CF(si, 3) = nb.x; CF(si, 4) = nb.y; CF(si, 5) = nb.z;
-                CF(si, 12) = vtarget;
-                CF(si, 13) = 0.f; CF(si, 14) = 0.f; CF(si, 15) = 0.f;
-                amask |= 1u << si;
-                if ((ndealt & 1) == (int)h) mym |= 1u << si;
-                ++ndealt;
-            }
-        }
-    }
+    // active slots of the pair, and the ones THIS lane takes through the sweeps: every other one in ascending order (bit i of px = parity of
+    // the active slots below i)
+    const unsigned amask = amine | (unsigned)__builtin_amdgcn_update_dpp(0, (int)amine, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+    unsigned px = amask << 1;
+    px ^= px << 1; px ^= px << 2; px ^= px << 4;
+    const unsigned mym = amask & (h ? px : ~px);
     PSTAMP(pr, 6);
     for (unsigned rem = amask; __any(rem != 0u); rem &= rem - 1u) {
         const bool valid = rem != 0u;
