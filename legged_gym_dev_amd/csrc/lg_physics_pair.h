@@ -131,6 +131,27 @@ struct SubProf {};
 #define PSTAMP(pr, k) do { } while (0)
 #endif
 
+// One contact's record as the sweeps use it, and one projected update of its three impulses (normal, then the two tangents against the
+// normal's change, then the friction cone): returns the impulse change in base coordinates.
+struct CRec { V3 Pc, nb, t1, t2; float iwn, w10, w20, iw1, w21, iw2, vt, ln, l1, l2; };
+__device__ __forceinline__ V3 contact_update(CRec &r, V3 vP, float relax, float mu, bool bounce, float rest /* 0.5 (e_shape + e_ground) */,
+                                             float bounce_threshold) {
+    float vc0 = dot(r.nb, vP), vc1 = dot(r.t1, vP), vc2 = dot(r.t2, vP);
+    if (bounce && vc0 < -bounce_threshold) r.vt = fmaxf(r.vt, -rest * vc0);      // restitution: leave with e x the approach speed
+    const float oln = r.ln, ol1 = r.l1, ol2 = r.l2;
+    const float ln = fmaxf(0.0f, oln - relax * (vc0 - r.vt) * r.iwn);
+    const float dn = ln - oln;
+    vc1 += r.w10 * dn;
+    vc2 += r.w20 * dn;
+    float l1 = ol1 - relax * vc1 * r.iw1;
+    vc2 += r.w21 * (l1 - ol1);
+    float l2 = ol2 - relax * vc2 * r.iw2;
+    const float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
+    if (mag > lim) { const float sc = lim * frcp(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
+    r.ln = ln; r.l1 = l1; r.l2 = l2;
+    return (ln - oln) * r.nb + (l1 - ol1) * r.t1 + (l2 - ol2) * r.t2;
+}
+
 #define LG_LKP_NF 12     // floats per link record shared by the pair: R 9, p 3
 #define LG_LKH_NF 6      // floats per link record per lane: my half of vel 3, of the velocity-product term 3
 
@@ -443,54 +464,87 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     PSTAMP(pr, 8);
     // ---- projected Jacobi sweeps
     if (__any((amask | lmask) != 0u)) {
+        // The scalar contact law needs no spatial algebra, so the pair does not share it: each lane takes every other active contact of the
+        // (env, leg) (mym, dealt at detection) -- a leg with n contacts costs ceil(n / 2) trips, and a launch lasts as long as its workgroup
+        // with the most contacts per leg (profiles/r04_substeps_spread.txt: fallen robots, 3-8 contacts per leg, set the launch's duration).
+        // Per trip the lanes swap what the other needs: the partner's half of the velocity of the link MY contact sits on, and the partner's half of
+        // the impulse I found.  DPP moves run outside the divergent part (they would read disabled partners inside it).
+        // The lane's FIRST contact -- the only one of a robot on its feet -- stays in registers for all iterations: no record reads, no
+        // impulse writes, no bit scan in the trip every sweep makes.
+        const bool a0 = mym != 0u;
+        const int si0 = a0 ? __ffs(mym) - 1 : 0;
+        const bool base0 = si0 >= LG_MAX_LEG_SLOTS;
+        const int jl0 = base0 ? -1 : (int)((link_pk >> (4 * si0)) & 15ull);
+        const int jlp0 = __builtin_amdgcn_update_dpp(0, jl0, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+        const float relax0 = base0 ? rb : rl;
+        CRec r0;
+        r0.Pc = {CF(si0, 0), CF(si0, 1), CF(si0, 2)}; r0.nb = {CF(si0, 3), CF(si0, 4), CF(si0, 5)};
+        r0.t1 = {CF(si0, 16), CF(si0, 17), CF(si0, 18)}; r0.t2 = cross(r0.nb, r0.t1);
+        r0.iwn = CF(si0, 6); r0.w10 = CF(si0, 7); r0.w20 = CF(si0, 8); r0.iw1 = CF(si0, 9); r0.w21 = CF(si0, 10); r0.iw2 = CF(si0, 11);
+        r0.vt = CF(si0, 12); r0.ln = 0.f; r0.l1 = 0.f; r0.l2 = 0.f;
+        const unsigned mrest = mym & (mym - 1u);
+        const float rest = c.material_rand ? 0.5f * (mat[0] + c.ground_restitution) : 0.f;
         for (int it = 0; it < c.solver_iterations; ++it) {
             V3 fimp[J], fb = zero3;
 #pragma unroll
             for (int k = 0; k < J; ++k) fimp[k] = zero3;
-            // The scalar contact law needs no spatial algebra, so the pair does not share it: each lane takes every other active contact of the
-            // (env, leg) (mym, dealt at detection) -- a leg with n contacts costs ceil(n / 2) trips, and a launch lasts as long as its workgroup
-            // with the most contacts per leg (profiles/r04_substeps_spread.txt: fallen robots, 3-8 contacts per leg, set the launch's duration).
-            // Per trip the lanes swap what the other needs: the partner's half of the velocity of the link MY contact sits on, and the partner's half of
-            // the impulse I found.  DPP moves run outside the divergent part (they would read disabled partners inside it).
-            for (unsigned rem = mym; __any(rem != 0u); rem &= rem - 1u) {
+            const bool bounce = c.material_rand && it == 0;
+            {   // first contact of the lane
+                V3 vm = velf0, vq = velf0;                      // my half of my contact's link, and of the partner's
+#pragma unroll
+                for (int k = 0; k < J; ++k) {
+                    if (jl0 == k) vm = velf[k];
+                    if (jlp0 == k) vq = velf[k];
+                }
+                const V3 vo = px3(vq);                          // the partner's half of MY contact's link
+                const V3 wl = sel3(h, vo, vm), vlin = sel3(h, vm, vo);
+                const V3 vP = vlin + cross(wl, r0.Pc);
+                V3 fmine = zero3, fsend = zero3;                // my half of the impulse of my contact, and the partner's half of it
+                if (a0) {
+                    const V3 dl = contact_update(r0, vP, relax0, mu, bounce, rest, c.bounce_threshold);
+                    const V3 tq = cross(r0.Pc, dl);
+                    fmine = sel3(h, dl, tq);
+                    fsend = sel3(h, tq, dl);
+                }
+                const V3 fget = px3(fsend);                     // my half of the partner's contact's impulse (zero if it has none)
+                if (base0) fb = fb + fmine;
+                if (jlp0 < 0) fb = fb + fget;
+#pragma unroll
+                for (int k = 0; k < J; ++k) {
+                    if (jl0 == k) fimp[k] = fimp[k] + fmine;
+                    if (jlp0 == k) fimp[k] = fimp[k] + fget;
+                }
+            }
+            for (unsigned rem = mrest; __any(rem != 0u); rem &= rem - 1u) {      // further contacts: records in the pair's LDS column
                 const bool active = rem != 0u;
                 const int si = active ? __ffs(rem) - 1 : 0;
                 const bool is_base = si >= LG_MAX_LEG_SLOTS;
                 const int jl = is_base ? -1 : (int)((link_pk >> (4 * si)) & 15ull);
                 const int jlp = __builtin_amdgcn_update_dpp(0, jl, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);     // the link of the partner's contact
-                V3 vm = velf0, vq = velf0;                      // my half of my contact's link, and of the partner's
+                V3 vm = velf0, vq = velf0;
 #pragma unroll
                 for (int k = 0; k < J; ++k) {
                     if (jl == k) vm = velf[k];
                     if (jlp == k) vq = velf[k];
                 }
-                const V3 vo = px3(vq);                          // the partner's half of MY contact's link
+                const V3 vo = px3(vq);
                 const V3 wl = sel3(h, vo, vm), vlin = sel3(h, vm, vo);
-                const V3 Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}, nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
-                const V3 vP = vlin + cross(wl, Pc);
-                V3 fmine = zero3, fsend = zero3;                // my half of the impulse of my contact, and the partner's half of it
+                CRec r;
+                r.Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}; r.nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
+                const V3 vP = vlin + cross(wl, r.Pc);
+                V3 fmine = zero3, fsend = zero3;
                 if (active) {
-                    const float oln = CF(si, 13), ol1 = CF(si, 14), ol2 = CF(si, 15), relax = is_base ? rb : rl;
-                    const V3 t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}, t2 = cross(nb, t1);
-                    float vc0 = dot(nb, vP), vc1 = dot(t1, vP), vc2 = dot(t2, vP);
-                    if (c.material_rand && it == 0 && vc0 < -c.bounce_threshold)      // restitution: leave with e x the approach speed
-                        CF(si, 12) = fmaxf(CF(si, 12), -0.5f * (mat[0] + c.ground_restitution) * vc0);
-                    float ln = fmaxf(0.0f, oln - relax * (vc0 - CF(si, 12)) * CF(si, 6));
-                    float dn = ln - oln;
-                    vc1 += CF(si, 7) * dn;
-                    vc2 += CF(si, 8) * dn;
-                    float l1 = ol1 - relax * vc1 * CF(si, 9);
-                    vc2 += CF(si, 10) * (l1 - ol1);
-                    float l2 = ol2 - relax * vc2 * CF(si, 11);
-                    float lim = mu * ln, mag = sqrtf(l1 * l1 + l2 * l2);
-                    if (mag > lim) { float sc = lim * frcp(fmaxf(mag, 1e-12f)); l1 *= sc; l2 *= sc; }
-                    const V3 dl = (ln - oln) * nb + (l1 - ol1) * t1 + (l2 - ol2) * t2;
-                    CF(si, 13) = ln; CF(si, 14) = l1; CF(si, 15) = l2;
-                    const V3 tq = cross(Pc, dl);
+                    r.t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}; r.t2 = cross(r.nb, r.t1);
+                    r.iwn = CF(si, 6); r.w10 = CF(si, 7); r.w20 = CF(si, 8); r.iw1 = CF(si, 9); r.w21 = CF(si, 10); r.iw2 = CF(si, 11);
+                    r.vt = CF(si, 12); r.ln = CF(si, 13); r.l1 = CF(si, 14); r.l2 = CF(si, 15);
+                    const V3 dl = contact_update(r, vP, is_base ? rb : rl, mu, bounce, rest, c.bounce_threshold);
+                    if (bounce) CF(si, 12) = r.vt;
+                    CF(si, 13) = r.ln; CF(si, 14) = r.l1; CF(si, 15) = r.l2;
+                    const V3 tq = cross(r.Pc, dl);
                     fmine = sel3(h, dl, tq);
                     fsend = sel3(h, tq, dl);
                 }
-                const V3 fget = px3(fsend);                     // my half of the partner's contact's impulse (zero if it had none this trip)
+                const V3 fget = px3(fsend);
                 if (is_base) fb = fb + fmine;
                 if (jlp < 0) fb = fb + fget;
 #pragma unroll
@@ -528,6 +582,7 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
                 qdf[k] += dq;
             }
         }
+        if (a0) { CF(si0, 13) = r0.ln; CF(si0, 14) = r0.l1; CF(si0, 15) = r0.l2; }      // for the force output below
     }
 
     PSTAMP(pr, 9);
