@@ -469,50 +469,63 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
         // with the most contacts per leg (profiles/r04_substeps_spread.txt: fallen robots, 3-8 contacts per leg, set the launch's duration).
         // Per trip the lanes swap what the other needs: the partner's half of the velocity of the link MY contact sits on, and the partner's half of
         // the impulse I found.  DPP moves run outside the divergent part (they would read disabled partners inside it).
-        // The lane's FIRST contact -- the only one of a robot on its feet -- stays in registers for all iterations: no record reads, no
-        // impulse writes, no bit scan in the trip every sweep makes.
-        const bool a0 = mym != 0u;
-        const int si0 = a0 ? __ffs(mym) - 1 : 0;
-        const bool base0 = si0 >= LG_MAX_LEG_SLOTS;
-        const int jl0 = base0 ? -1 : (int)((link_pk >> (4 * si0)) & 15ull);
-        const int jlp0 = __builtin_amdgcn_update_dpp(0, jl0, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
-        const float relax0 = base0 ? rb : rl;
-        CRec r0;
-        r0.Pc = {CF(si0, 0), CF(si0, 1), CF(si0, 2)}; r0.nb = {CF(si0, 3), CF(si0, 4), CF(si0, 5)};
-        r0.t1 = {CF(si0, 16), CF(si0, 17), CF(si0, 18)}; r0.t2 = cross(r0.nb, r0.t1);
-        r0.iwn = CF(si0, 6); r0.w10 = CF(si0, 7); r0.w20 = CF(si0, 8); r0.iw1 = CF(si0, 9); r0.w21 = CF(si0, 10); r0.iw2 = CF(si0, 11);
-        r0.vt = CF(si0, 12); r0.ln = 0.f; r0.l1 = 0.f; r0.l2 = 0.f;
-        const unsigned mrest = mym & (mym - 1u);
+        // The lane's first two contacts -- a robot on its feet has one per leg -- stay in registers for all iterations: no record reads, no
+        // impulse writes, no bit scan in the trips nearly every sweep consists of; the second trip is skipped when no lane of the wave has one.
+        constexpr int NRC = J <= 3 ? 2 : 1;                     // contacts per lane held in registers (two lanes: up to four per leg); one for the
+                                                                // six-joint legs, whose chain state already fills the register file (Cassie: 113 -> 116 us with two)
+        bool ra[NRC], rbase[NRC];
+        int rsi[NRC], rjl[NRC], rjlp[NRC];
+        float rrelax[NRC];
+        CRec rr[NRC];
+        unsigned mrest = mym;
+#pragma unroll
+        for (int t = 0; t < NRC; ++t) {
+            ra[t] = mrest != 0u;
+            rsi[t] = ra[t] ? __ffs(mrest) - 1 : 0;
+            rbase[t] = rsi[t] >= LG_MAX_LEG_SLOTS;
+            rjl[t] = rbase[t] ? -1 : (int)((link_pk >> (4 * rsi[t])) & 15ull);
+            rjlp[t] = __builtin_amdgcn_update_dpp(0, rjl[t], 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+            rrelax[t] = rbase[t] ? rb : rl;
+            const int si = rsi[t];
+            CRec &r = rr[t];
+            r.Pc = {CF(si, 0), CF(si, 1), CF(si, 2)}; r.nb = {CF(si, 3), CF(si, 4), CF(si, 5)};
+            r.t1 = {CF(si, 16), CF(si, 17), CF(si, 18)}; r.t2 = cross(r.nb, r.t1);
+            r.iwn = CF(si, 6); r.w10 = CF(si, 7); r.w20 = CF(si, 8); r.iw1 = CF(si, 9); r.w21 = CF(si, 10); r.iw2 = CF(si, 11);
+            r.vt = CF(si, 12); r.ln = 0.f; r.l1 = 0.f; r.l2 = 0.f;
+            mrest &= mrest - 1u;
+        }
         const float rest = c.material_rand ? 0.5f * (mat[0] + c.ground_restitution) : 0.f;
         for (int it = 0; it < c.solver_iterations; ++it) {
             V3 fimp[J], fb = zero3;
 #pragma unroll
             for (int k = 0; k < J; ++k) fimp[k] = zero3;
             const bool bounce = c.material_rand && it == 0;
-            {   // first contact of the lane
+#pragma unroll
+            for (int t = 0; t < NRC; ++t) {                     // the lane's first contacts, from registers
+                if (t > 0 && !__any(ra[t])) continue;
                 V3 vm = velf0, vq = velf0;                      // my half of my contact's link, and of the partner's
 #pragma unroll
                 for (int k = 0; k < J; ++k) {
-                    if (jl0 == k) vm = velf[k];
-                    if (jlp0 == k) vq = velf[k];
+                    if (rjl[t] == k) vm = velf[k];
+                    if (rjlp[t] == k) vq = velf[k];
                 }
                 const V3 vo = px3(vq);                          // the partner's half of MY contact's link
                 const V3 wl = sel3(h, vo, vm), vlin = sel3(h, vm, vo);
-                const V3 vP = vlin + cross(wl, r0.Pc);
+                const V3 vP = vlin + cross(wl, rr[t].Pc);
                 V3 fmine = zero3, fsend = zero3;                // my half of the impulse of my contact, and the partner's half of it
-                if (a0) {
-                    const V3 dl = contact_update(r0, vP, relax0, mu, bounce, rest, c.bounce_threshold);
-                    const V3 tq = cross(r0.Pc, dl);
+                if (ra[t]) {
+                    const V3 dl = contact_update(rr[t], vP, rrelax[t], mu, bounce, rest, c.bounce_threshold);
+                    const V3 tq = cross(rr[t].Pc, dl);
                     fmine = sel3(h, dl, tq);
                     fsend = sel3(h, tq, dl);
                 }
                 const V3 fget = px3(fsend);                     // my half of the partner's contact's impulse (zero if it has none)
-                if (base0) fb = fb + fmine;
-                if (jlp0 < 0) fb = fb + fget;
+                if (rbase[t]) fb = fb + fmine;
+                if (rjlp[t] < 0) fb = fb + fget;
 #pragma unroll
                 for (int k = 0; k < J; ++k) {
-                    if (jl0 == k) fimp[k] = fimp[k] + fmine;
-                    if (jlp0 == k) fimp[k] = fimp[k] + fget;
+                    if (rjl[t] == k) fimp[k] = fimp[k] + fmine;
+                    if (rjlp[t] == k) fimp[k] = fimp[k] + fget;
                 }
             }
             for (unsigned rem = mrest; __any(rem != 0u); rem &= rem - 1u) {      // further contacts: records in the pair's LDS column
@@ -582,7 +595,9 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
                 qdf[k] += dq;
             }
         }
-        if (a0) { CF(si0, 13) = r0.ln; CF(si0, 14) = r0.l1; CF(si0, 15) = r0.l2; }      // for the force output below
+#pragma unroll
+        for (int t = 0; t < NRC; ++t)
+            if (ra[t]) { CF(rsi[t], 13) = rr[t].ln; CF(rsi[t], 14) = rr[t].l1; CF(rsi[t], 15) = rr[t].l2; }      // for the force output below
     }
 
     PSTAMP(pr, 9);
