@@ -117,29 +117,14 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
 // per CU that larger env counts use.
 #define LG_RUN_TORQUES 1
 #define LG_RUN_PHYSICS 2
-__device__ int g_substeps_pwsel = 0;
-// which of the (up to two) co-resident workgroups of this CU: the workgroup's slot in the CU (HW_ID.TG_ID) -- or by dispatch order
-__device__ __forceinline__ int substeps_second(int sel) {
-    if (sel & 8) return __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1;
-    return (blockIdx.x / (gridDim.x / 2)) & 1;
-}
-template <int NW, int PWX>
-__device__ __forceinline__ int substeps_phys_wave() {
-    const int sel = g_substeps_pwsel;
-    if ((sel & 3) == 0) return 0;
-    const int second = substeps_second(sel);
-    if ((sel & 3) == 1) return second ? 2 : 0;
-    if ((sel & 3) == 2) return second ? 1 : 0;
-    return second ? 3 : 0;
-}
-template <int L, int J, bool LSTM, bool PAIR, int NW = 4, int PWX = 0>
+template <int L, int J, bool LSTM, bool PAIR, int NW = 4>
 __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
     // NW waves per block.  NW = 4: two physics waves (pair-lane map) + two that only run the actuator net, 64/L envs.  NW = 2 (pair-lane
     // map only): one physics wave + one actuator-net wave, 32/L envs -- two such blocks per CU, and no physics wave ever waits at a
     // substep barrier for the other one's contacts (LG_SUBSTEPS_NW).
     static_assert(NW == 4 || (NW == 2 && PAIR), "block shapes: 4 waves, or 2 waves with the pair-lane physics");
     constexpr int NT = 64 * NW, RPP = NT / 8;                   // threads; actuator-net rows per pass (8 lanes per row)
-    constexpr int PW = PWX ? PWX : PAIR ? NW / 2 : 1, LPE = PAIR ? 2 * L : L;    // physics waves of the block, physics lanes per env
+    constexpr int PW = PAIR ? NW / 2 : 1, LPE = PAIR ? 2 * L : L;    // physics waves of the block, physics lanes per env
     constexpr int A = L * J, EPW = 64 * PW / LPE, ROWS = EPW * A, NR = ROWS * 8 / NT;
     const lg_cfg &c = P->cfg;
     const lg_model &m = P->model;
@@ -191,8 +176,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
     }
     // physics lanes: wave 0, one lane per (env, leg) -- or waves 0 and 1, two lanes per (env, leg) (lg_physics_pair.h);
     // of a pair, lane h = 0 does the stores
-    const int pw0 = PWX ? substeps_phys_wave<NW, PWX>() : 0, ptid = (tid - 64 * pw0) & (64 * PW - 1);
-    const bool phys = wave >= pw0 && wave < pw0 + PW, hrole = PAIR && (ptid & 1), writer = !hrole;
+    const int ptid = tid & (64 * PW - 1);
+    const bool phys = wave < PW, hrole = PAIR && (ptid & 1), writer = !hrole;
     const int pe = ptid / LPE;                               // env of this lane within the block
     int env = env0 + pe;
     const int leg = PAIR ? (ptid >> 1) % L : ptid % L;
@@ -207,6 +192,34 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
         for (int k = 0; k < 13; ++k) root[k] = rp[k];
         fr = P->buf.friction[env]; dm = P->buf.base_mass_delta[env];
     }
+    // per-launch constants of the loop, fetched once and BEFORE the barrier, with everything else this launch reads from memory: a global
+    // load inside the substep loop is a round trip to the L2 on the critical path of every substep (the compiler does not hoist them past
+    // the LDS traffic: six serialised loads per actuator-net pass, seven in the contact-force accumulation -- found in the ISA, round 4)
+    const PhysCfg pk = phys_cfg(P);            // the physics' launch constants, in registers for the whole control loop
+    const float action_scale = c.action_scale;
+    const int control_type = c.control_type;
+    const float sim_dt = c.sim_dt;
+    float qtgt[NR];                                                              // AN:72  actions * scale + default_dof_pos
+    if (LSTM && do_tau) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) qtgt[r] = c.default_dof_pos[(r * RPP + (tid >> 3)) % A];
+    }
+    float kp[J], kd[J], tlim[J], ptgt[J], lqd[J];                                // LR:389-413: gains, limits and the target of this lane's joints
+    if (!LSTM && do_tau && phys) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int d = leg * J + j;
+            kp[j] = c.p_gains[d]; kd[j] = c.d_gains[d]; tlim[j] = c.torque_limits[d];
+            ptgt[j] = control_type == 0 ? c.default_dof_pos[d] : 0.f;
+            lqd[j] = control_type == 1 ? P->buf.last_dof_vel[(size_t)env * A + d] : 0.f;
+        }
+    }
+    int slot_body[LG_MAX_LEG_SLOTS], base_body0 = 0;
+    if (do_phys && phys) {
+#pragma unroll
+        for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k) slot_body[k] = k < pk.n_leg_slots ? P->slot_body[k][leg] : 0;
+        base_body0 = P->base_body[0];
+    }
     __syncthreads();
     if (phys) {
 #pragma unroll
@@ -218,43 +231,19 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
     const int ns = c.phys_substeps > 1 ? c.phys_substeps : 1;
     const float dt = c.sim_dt / (float)ns, wgt = 1.0f / (float)ns;
     float *cf = s_cf + pe * B * 3;
-    const PhysCfg pk = phys_cfg(P);            // the physics' launch constants, in registers for the whole control loop
-    const float action_scale = c.action_scale;
-    // per-launch constants of the loop, fetched once: a global load inside the substep loop is a round trip to the L2 on the critical
-    // path of every substep (the compiler does not hoist them past the LDS traffic: six serialised loads per actuator-net pass, seven in
-    // the contact-force accumulation -- found in the ISA, round 4)
-    float qtgt[NR];                                                              // AN:72  actions * scale + default_dof_pos
     if (LSTM && do_tau) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int rl = r * RPP + (tid >> 3);
-            qtgt[r] = s_act[rl] * action_scale + c.default_dof_pos[rl % A];
-        }
+        for (int r = 0; r < NR; ++r) qtgt[r] = s_act[r * RPP + (tid >> 3)] * action_scale + qtgt[r];
     }
-    float kp[J], kd[J], tlim[J], ptgt[J], lqd[J];                                // LR:389-413: gains, limits and the target of this lane's joints
-    const int control_type = c.control_type;
-    const float sim_dt = c.sim_dt;
     if (!LSTM && do_tau && phys) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const int d = leg * J + j;
             const float as = s_act[live ? rl0 + j : 0] * action_scale;
-            kp[j] = c.p_gains[d]; kd[j] = c.d_gains[d]; tlim[j] = c.torque_limits[d];
-            ptgt[j] = control_type == 0 ? as + c.default_dof_pos[d] : as;
-            lqd[j] = control_type == 1 ? P->buf.last_dof_vel[(size_t)env * A + d] : 0.f;
+            ptgt[j] = control_type == 0 ? as + ptgt[j] : as;
         }
     }
-    int slot_body[LG_MAX_LEG_SLOTS], base_body0 = 0;
-    if (do_phys && phys) {
-#pragma unroll
-        for (int k = 0; k < LG_MAX_LEG_SLOTS; ++k) slot_body[k] = k < pk.n_leg_slots ? P->slot_body[k][leg] : 0;
-        base_body0 = P->base_body[0];
-    }
     PSTAMP(pr, 0);
-    const int stag = PWX ? g_substeps_pwsel : 0;
-    if (PWX && (stag & 16) && substeps_second(stag)) for (int k = 0; k < (stag >> 8); ++k) __builtin_amdgcn_s_sleep(64);
     for (int sub = 0; sub < iters; ++sub) {
-        if (PWX && (stag & 4)) { if (sub == 0 && substeps_second(stag)) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
         // ---- torques
         if (do_tau) {
             if (LSTM) {                                                      // AN:71-81
@@ -290,7 +279,6 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
         PSTAMP(pr, 1);
         // ---- physics
         if (do_phys && phys) {
-            if (PWX && (stag & 32)) __builtin_amdgcn_s_setprio(3);
             const bool last = sub == iters - 1;
             for (int s = 0; s < ns; ++s) {
                 V3 fslot[LG_MAX_LEG_SLOTS], fbase;
@@ -324,7 +312,6 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
                 for (int j = 0; j < J; ++j) { s_q[rl0 + j] = q[j]; s_qd[rl0 + j] = qd[j]; }
             }
         }
-        if (PWX && (stag & 32)) __builtin_amdgcn_s_setprio(0);
         PSTAMP(pr, 12);
         __syncthreads();
         PSTAMP(pr, 13);
@@ -355,7 +342,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__rest
     PSTAMP(pr, 14);
     pr.acc[15] = __builtin_amdgcn_s_memrealtime() - prof_rt0;
 #ifdef LG_PROF_SPAN        // every workgroup's first and last tick of the chip-wide 100 MHz clock (tools/substeps_span.py): dispatch skew and tail
-    if (tid == 64 * pw0 && blockIdx.x < 256) { P->dbg_cycles[blockIdx.x * 2] = prof_rt0; P->dbg_cycles[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
+    if (tid == 0 && blockIdx.x < 256) { P->dbg_cycles[blockIdx.x * 2] = prof_rt0; P->dbg_cycles[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); }
 #else
     if ((tid & 63) == 0 && wave < 2 && blockIdx.x < 16)
         for (int k = 0; k < 16; ++k) P->dbg_cycles[(blockIdx.x * 2 + wave) * 16 + k] = pr.acc[k];
@@ -1118,16 +1105,13 @@ static int phys_pair_enabled() {
 // nothing, the chain per wave is the same); biped 148.7 (4: 128 blocks, half the CUs idle) vs 145.5 us (2: 256 blocks).  Results are
 // bit-identical either way (tests/test_hip_env.py::test_control_loop_block_shapes_are_bit_identical).
 static int g_substeps_nw = -1;
-extern "C" void lgk_debug_set_substeps_nw(int v) { g_substeps_nw = v == 2 ? 2 : v == 4 ? 4 : v == 41 ? 41 : 0; }
+extern "C" void lgk_debug_set_substeps_nw(int v) { g_substeps_nw = v == 2 ? 2 : v == 4 ? 4 : 0; }
 template <int L, int J, bool LSTM>
 static void launch_substeps(int N, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {
-    if (g_substeps_nw < 0) { const char *e = getenv("LG_SUBSTEPS_NW"); g_substeps_nw = e ? (atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : atoi(e) == 41 ? 41 : 0) : 0;
-        if (const char *q = getenv("LG_SUBSTEPS_PWSEL")) { int v = atoi(q); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_substeps_pwsel), &v, sizeof v); } }
+    if (g_substeps_nw < 0) { const char *e = getenv("LG_SUBSTEPS_NW"); g_substeps_nw = e ? (atoi(e) == 2 ? 2 : atoi(e) == 4 ? 4 : 0) : 0; }
     const int epw4 = 64 / L, epw2 = 32 / L;
     const int nw = g_substeps_nw ? g_substeps_nw : (L == 2 ? 2 : 4);
-    if (phys_pair_enabled() && nw == 41)
-        hipLaunchKernelGGL((k_substeps<L, J, LSTM, true, 4, 1>), dim3((N + epw2 - 1) / epw2), dim3(256), 0, s, P, a_in, mode, iters);
-    else if (phys_pair_enabled() && nw == 2)
+    if (phys_pair_enabled() && nw == 2)
         hipLaunchKernelGGL((k_substeps<L, J, LSTM, true, 2>), dim3((N + epw2 - 1) / epw2), dim3(128), 0, s, P, a_in, mode, iters);
     else if (phys_pair_enabled())
         hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3((N + epw4 - 1) / epw4), dim3(256), 0, s, P, a_in, mode, iters);

@@ -250,9 +250,8 @@ def test_fused_control_loop_equals_launch_per_substep(name):
         b.close()
 
 
-@pytest.mark.parametrize("shape", [2, 41])
 @pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
-def test_control_loop_block_shapes_are_bit_identical(name, shape):
+def test_control_loop_block_shapes_are_bit_identical(name):
     """The control loop on blocks of 4 waves (two physics waves, 64/L envs) against blocks of 2 waves (one physics wave, 32/L envs:
     LG_SUBSTEPS_NW=2): which workgroup an environment lands in and how many waves share its barriers must not change a bit of
     its state -- 133 envs (ragged last block in both shapes), 6 policy steps with contacts and resets."""
@@ -282,7 +281,7 @@ def test_control_loop_block_shapes_are_bit_identical(name, shape):
             act = rng.uniform(-3, 3, (n, A)).astype(np.float32)
             lib.lg_debug_set_substeps_nw(4)
             a.step(act)
-            lib.lg_debug_set_substeps_nw(shape)
+            lib.lg_debug_set_substeps_nw(2)
             b.step(act)
             for key in ("reset", "episode_length", "torques", "dof_state", "root_states", "obs", "rew", "lstm_h", "lstm_c",
                         "contact_forces", "feet_air_time"):
