@@ -1510,105 +1510,142 @@ __global__ void __launch_bounds__(256) k_head_fused(PpoDev P, const float *__res
 
 // The same fused head with one network per workgroup (blockIdx.y: 0 actor, 1 critic).  The two heads share nothing but the
 // row index -- surrogate / entropy / KL need mu only, the value loss needs V only -- so each workgroup stages ONE activation
-// tile: 43 KB of LDS instead of 84, two workgroups per CU instead of one on 192 of the 256 CUs.  Used for H3 = 128, where
+// tile: 50 KB of LDS instead of 84, three workgroups per CU (all 768 of a 24576-row minibatch resident).  Used for H3 = 128, where
 // k_head_fused is one wave per SIMD.
-template <int H3>
-__global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__restrict__ xa_g, const float *__restrict__ xc_g,
-                                                     float *__restrict__ dza_g, float *__restrict__ dzc_g, int64_t w_a, int64_t b_a,
-                                                     int64_t w_c, int64_t b_c, int64_t b_prev_a, int64_t b_prev_c) {
-    constexpr int MA = LG_PPO_MAX_A, LDX = H3 + 1, NH = 256 / H3;
-    const int R = P.mb_rows, A = P.A, tid = threadIdx.x;
+//
+// Round 4: the arithmetic is the old kernel's, the operand paths are not.  With a row per lane and the head weights and the rows'
+// output gradients read from LDS for every multiply-add, the kernel moved 1.25 LDS dwords per FMA and the twelve waves of a CU queued
+// on the LDS port for 13 us of its 29.  Now every operand that is uniform over a wave comes through the SCALAR path:
+//   forward   lane = row, wave = a quarter of k; the weights are wave-uniform and arrive by s_load from global memory (K$), 32 x reads
+//             per lane instead of 640; the four partial sums per (row, output) meet in LDS, added in a fixed order
+//   loss      every wave evaluates the 64 rows (lane = row), so each wave holds d loss / d out of all rows in its own registers; wave 0
+//             alone accumulates the row sums
+//   backward  wave = every fourth row, lane = columns (lane, lane + 64): a row's output gradients are v_readlane'd into SGPRs and feed
+//             the multiply-adds as scalar operands; one LDS read per column and row
+template <int H3, int NA>
+__global__ void __launch_bounds__(256, 3) k_head_net(PpoDev P, const float *__restrict__ xa_g, const float *__restrict__ xc_g,
+                                                     float *__restrict__ dza_g, float *__restrict__ dzc_g, const float *__restrict__ wa_g,
+                                                     const float *__restrict__ wc_g, int64_t b_a, int64_t b_c) {
+    static_assert(H3 == 128, "lane = columns (lane, lane + 64); wave = a quarter of k");
+    static_assert(NA <= LG_PPO_MAX_A, "NA = the action count the register arrays are sized for (>= P.A); the scratch row keeps LG_PPO_MAX_A slots");
+    constexpr int MA = LG_PPO_MAX_A, LDX = H3 + 1, NWV = 4, KQ = H3 / NWV;
+    const int R = P.mb_rows, A = P.A, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool actor = blockIdx.y == 0;
     const float *__restrict__ x_g = actor ? xa_g : xc_g;
+    const float *__restrict__ w_g = actor ? wa_g : wc_g;
     float *__restrict__ dz_g = actor ? dza_g : dzc_g;
     const int nout = actor ? A : 1;
-    __shared__ float x[HEAD_ROWS * LDX];
-    __shared__ float w[MA * H3];
-    __shared__ float outs[HEAD_ROWS][MA + 1];
-    __shared__ __attribute__((aligned(16))) float douts[HEAD_ROWS][MA + 4];   // rows of 20 floats: the backward reads them as four b128
-    __shared__ float red[2 * MA + 4], s_so2[MA], s_i2s2[MA], s_is2[MA], s_is[MA], s_lgs[MA], s_klc[MA];
+    // x tile, then the partial outputs [NWV][HEAD_ROWS][NA + 1]; after the tile loop the same floats hold the column sums and the row sums.
+    // s_am: the tile's rows of the minibatch's actions and old means, staged with the tile (the loss lanes' own loads of them sank to
+    // their use under the 168-register cap and cost the actor's loss phase 6 us of exposed latency: stamps, round 4)
+    // (52.9 KB in all: three workgroups per CU is 158.8 of the 160 KB -- one more KB and a third of the workgroups start a round late)
+    constexpr int OP = NA + 1, NBUF = HEAD_ROWS * LDX + NWV * HEAD_ROWS * OP;
+    __shared__ float buf[NBUF];
+    __shared__ float s_am[2 * HEAD_ROWS * NA];
+    __shared__ float s_so2[MA], s_i2s2[MA], s_is2[MA], s_is[MA], s_lgs[MA], s_klc[MA], s_bias[MA];
+    float *x = buf, *outs_p = buf + HEAD_ROWS * LDX;
     if (tid < MA) {
         const float sg = tid < A ? P.params[P.off_std + tid] : 1.f, so = tid < A ? P.st_sigma[tid] : 1.f;
         s_so2[tid] = so * so; s_i2s2[tid] = 1.0f / (2.0f * sg * sg); s_is2[tid] = 1.0f / (sg * sg); s_is[tid] = 1.0f / sg;
         s_lgs[tid] = logf(sg) + 0.9189385332046727f; s_klc[tid] = logf(sg / so + 1.e-5f) - 0.5f;
+        s_bias[tid] = tid < nout ? P.params[(actor ? b_a : b_c) + tid] : 0.f;
     }
-    for (int i = tid; i < nout * H3; i += 256) w[i] = P.params[(actor ? w_a : w_c) + i];
-    if (tid < 2 * MA + 4) red[tid] = 0.f;
-    const int c = tid % H3, half = tid / H3;
-    float dw[MA], db_prev = 0.f, part[2 * MA + 4];
+    float wcol0[NA], wcol1[NA];                             // the head weights of this lane's two columns (backward)
 #pragma unroll
-    for (int a = 0; a < MA; ++a) dw[a] = 0.f;
+    for (int a = 0; a < NA; ++a) {
+        wcol0[a] = a < nout ? w_g[a * H3 + lane] : 0.f;
+        wcol1[a] = a < nout ? w_g[a * H3 + lane + 64] : 0.f;
+    }
+    float dw0[NA], dw1[NA], db0 = 0.f, db1 = 0.f, part[2 * MA + 4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { dw0[a] = 0.f; dw1[a] = 0.f; }
 #pragma unroll
     for (int k = 0; k < 2 * MA + 4; ++k) part[k] = 0.f;
     const int ntiles = (R + HEAD_ROWS - 1) / HEAD_ROWS;
     const float invR = 1.0f / (float)R;
+#ifdef LG_HEAD_STAMPS
+    unsigned long long ts[8]; ts[0] = __builtin_amdgcn_s_memrealtime();
+#define HSTAMP(k) ts[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define HSTAMP(k) do { } while (0)
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int r0 = tile * HEAD_ROWS;
+        // what the loss needs of this lane's row, requested before anything waits
+        const int r = r0 + lane;
+        const size_t rr = (size_t)min(r, R - 1);
+        const float4 sc = reinterpret_cast<const float4 *>(P.mb_scalars)[rr];
         __syncthreads();
+        if (actor) {                                        // rows r0 .. r0 + 63 of [R][A]: one contiguous run
+            const size_t base = (size_t)r0 * A, lim = (size_t)R * A;
+            for (int i = tid; i < HEAD_ROWS * A; i += 256) {
+                const size_t g = base + i < lim ? base + i : lim - 1;
+                s_am[i] = P.mb_actions[g];
+                s_am[HEAD_ROWS * NA + i] = P.mb_mu[g];
+            }
+        }
         {
             constexpr int NV = HEAD_ROWS * H3 / 4 / 256;
             float4 vx[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const int i = tid + v * 256, r = i / (H3 / 4), c4 = i % (H3 / 4);
-                vx[v] = *reinterpret_cast<const float4 *>(x_g + (size_t)min(r0 + r, R - 1) * H3 + 4 * c4);
+                const int i = tid + v * 256, rw = i / (H3 / 4), c4 = i % (H3 / 4);
+                vx[v] = *reinterpret_cast<const float4 *>(x_g + (size_t)min(r0 + rw, R - 1) * H3 + 4 * c4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const int i = tid + v * 256, r = i / (H3 / 4), c4 = i % (H3 / 4);
-                float *d = x + r * LDX + 4 * c4;
+                const int i = tid + v * 256, rw = i / (H3 / 4), c4 = i % (H3 / 4);
+                float *d = x + rw * LDX + 4 * c4;
                 d[0] = vx[v].x; d[1] = vx[v].y; d[2] = vx[v].z; d[3] = vx[v].w;
             }
         }
         __syncthreads();
-        {   // forward: lane = row; wave wv takes outputs wv, wv + 4, ... (critic: the four waves split k and meet in LDS)
-            const int r = tid & 63, wv = tid >> 6;
-            const float *xr = x + r * LDX;
-            if (actor) {
-                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-                const float *w0 = w + (wv < A ? wv : 0) * H3, *w1 = w + (wv + 4 < A ? wv + 4 : 0) * H3;
-                const float *w2 = w + (wv + 8 < A ? wv + 8 : 0) * H3, *w3 = w + (wv + 12 < A ? wv + 12 : 0) * H3;
-#pragma unroll 8
-                for (int k = 0; k < H3; ++k) {
-                    const float xv = xr[k];
-                    o0 += xv * w0[k]; o1 += xv * w1[k]; o2 += xv * w2[k]; o3 += xv * w3[k];
+        HSTAMP(1);
+        {   // forward: lane = row, wave = k quarter; weights through the scalar cache.  One guard per output (not per multiply-add group):
+            // the scheduler works inside basic blocks, and a row's 32 activations stay in registers across the outputs
+            const float *xr = x + lane * LDX + KQ * wv;
+            const float *__restrict__ wq = w_g + KQ * wv;
+            float xv[KQ];
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) xv[j] = xr[j];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                if (a < nout) {
+                    float o = 0.f;
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) o = __builtin_fmaf(xv[j], wq[a * H3 + j], o);
+                    outs_p[(wv * HEAD_ROWS + lane) * OP + a] = o;
                 }
-                if (wv < A) outs[r][wv] = o0 + P.params[b_a + wv];
-                if (wv + 4 < A) outs[r][wv + 4] = o1 + P.params[b_a + wv + 4];
-                if (wv + 8 < A) outs[r][wv + 8] = o2 + P.params[b_a + wv + 8];
-                if (wv + 12 < A) outs[r][wv + 12] = o3 + P.params[b_a + wv + 12];
-            } else {
-                float o = 0.f;
-#pragma unroll 8
-                for (int k = wv * (H3 / 4); k < (wv + 1) * (H3 / 4); ++k) o += xr[k] * w[k];
-                outs[r][wv] = o;                            // four partial sums per row
-            }
         }
         __syncthreads();
-        if (tid < HEAD_ROWS) {                              // loss of one row (the arithmetic of k_loss), wave 0
-            const int r = r0 + tid;
-            const size_t rr = (size_t)min(r, R - 1);
-            const float4 sc = reinterpret_cast<const float4 *>(P.mb_scalars)[rr];
+        HSTAMP(2);
+        float dout[NA];                                     // d loss / d out of row `lane`, in every wave
 #pragma unroll
-            for (int a = 0; a <= MA; ++a) douts[tid][a] = 0.f;
-            if (actor) {
-                float act_r[MA], mo_r[MA];
+        for (int a = 0; a < NA; ++a) dout[a] = 0.f;
+        {
+            float outv[NA];
 #pragma unroll
-                for (int a = 0; a < MA; ++a) {
-                    const int ac = min(a, A - 1);
-                    act_r[a] = P.mb_actions[rr * A + ac];
-                    mo_r[a] = P.mb_mu[rr * A + ac];
+            for (int a = 0; a < NA; ++a) {
+                outv[a] = 0.f;
+                if (a < nout) {
+                    const float *op = outs_p + lane * OP + a;
+                    constexpr int QS = HEAD_ROWS * OP;
+                    outv[a] = (op[0] + op[QS]) + (op[2 * QS] + op[3 * QS]);
                 }
+            }
+            const bool sums = wv == 0;                      // the row sums are wave 0's
+            if (actor) {
                 if (r < R) {
                     const float adv = sc.z, lp_old = sc.w;
-                    float lp = 0.f, kl = 0.f, dd[MA];
+                    float lp = 0.f, kl = 0.f, dd[NA];
 #pragma unroll
-                    for (int a = 0; a < MA; ++a) {
+                    for (int a = 0; a < NA; ++a) {
                         dd[a] = 0.f;
                         if (a < A) {
-                            const float m = outs[tid][a], mo = mo_r[a];
-                            const float d = act_r[a] - m;
+                            const float m = outv[a] + s_bias[a], mo = s_am[HEAD_ROWS * NA + lane * A + a];
+                            const float d = s_am[lane * A + a] - m;
                             dd[a] = d;
                             lp += -(d * d) * s_i2s2[a] - s_lgs[a];
                             kl += s_klc[a] + (s_so2[a] + (mo - m) * (mo - m)) * s_i2s2[a];
@@ -1619,20 +1656,21 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
                     const float s1 = -adv * ratio, s2 = -adv * rc;
                     const float dl_dlp = (s1 >= s2 ? -adv : 0.0f) * ratio * invR;
 #pragma unroll
-                    for (int a = 0; a < MA; ++a)
+                    for (int a = 0; a < NA; ++a)
                         if (a < A) {
                             const float d = dd[a];
                             const float g = dl_dlp * d * s_is2[a];
-                            douts[tid][a] = g;
-                            part[MA + a] += g;
-                            part[a] += dl_dlp * (d * d * s_is2[a] * s_is[a] - s_is[a]) - P.entropy_coef * invR * s_is[a];
+                            dout[a] = g;
+                            if (sums) {
+                                part[MA + a] += g;
+                                part[a] += dl_dlp * (d * d * s_is2[a] * s_is[a] - s_is[a]) - P.entropy_coef * invR * s_is[a];
+                            }
                         }
-                    part[2 * MA + 1] += kl;
-                    part[2 * MA + 3] += fmaxf(s1, s2);
+                    if (sums) { part[2 * MA + 1] += kl; part[2 * MA + 3] += fmaxf(s1, s2); }
                 }
             } else if (r < R) {
                 const float v_old = sc.x, ret = sc.y;
-                const float v = P.params[b_c] + ((outs[tid][0] + outs[tid][1]) + (outs[tid][2] + outs[tid][3]));
+                const float v = s_bias[0] + outv[0];
                 float lv, dv;
                 if (P.clipped_value) {
                     const float dvv = v - v_old;
@@ -1648,72 +1686,69 @@ __global__ void __launch_bounds__(256, 2) k_head_net(PpoDev P, const float *__re
                     dv = 2.0f * (v - ret);
                 }
                 const float dvl = dv * P.value_coef * invR;
-                douts[tid][0] = dvl;
-                part[2 * MA] += dvl;
-                part[2 * MA + 2] += lv;
+                dout[0] = dvl;
+                if (sums) { part[2 * MA] += dvl; part[2 * MA + 2] += lv; }
             }
         }
-        __syncthreads();
-        if (half < NH) {                                    // backward for column c: dz = (dout . W) act'(x); dW += dout^T x
-            float wcol[MA];
+        // backward for rows wv, wv + 4, ...: dz = (dout . W) act'(x); dW += dout^T x; the row's dout as scalars.  Written twice: without
+        // the per-output guard when the register arrays are exactly as long as the head is wide (the actor of every registered task)
+        HSTAMP(3);
+        auto backward = [&](auto full) {
+            for (int rw = wv; rw < HEAD_ROWS && r0 + rw < R; rw += NWV) {
+                const float xv0 = x[rw * LDX + lane], xv1 = x[rw * LDX + lane + 64];
+                float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-            for (int a = 0; a < MA; ++a) wcol[a] = a < nout ? w[a * H3 + c] : 0.f;
-            for (int r = half; r < HEAD_ROWS && r0 + r < R; r += NH) {
-                const float xv = x[r * LDX + c];
-                float g = 0.f;
-                if (actor) {
-                    float dmv[MA];
-#pragma unroll
-                    for (int a4 = 0; a4 < MA / 4; ++a4) {
-                        const float4 t = reinterpret_cast<const float4 *>(douts[r])[a4];
-                        dmv[4 * a4] = t.x; dmv[4 * a4 + 1] = t.y; dmv[4 * a4 + 2] = t.z; dmv[4 * a4 + 3] = t.w;
+                for (int a = 0; a < NA; ++a)
+                    if (decltype(full)::value || a < nout) {
+                        const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dout[a]), rw));
+                        g0 = __builtin_fmaf(sa, wcol0[a], g0); g1 = __builtin_fmaf(sa, wcol1[a], g1);
+                        dw0[a] = __builtin_fmaf(sa, xv0, dw0[a]); dw1[a] = __builtin_fmaf(sa, xv1, dw1[a]);
                     }
-#pragma unroll
-                    for (int a = 0; a < MA; ++a) {
-                        g += dmv[a] * wcol[a];
-                        dw[a] += dmv[a] * xv;
-                    }
-                } else {
-                    const float dv = douts[r][0];
-                    g = dv * wcol[0];
-                    dw[0] += dv * xv;
-                }
-                const float dz = g * (xv > 0.f ? 1.0f : xv + 1.0f);
-                dz_g[(size_t)(r0 + r) * H3 + c] = dz;
-                db_prev += dz;
+                const float dz0 = g0 * (xv0 > 0.f ? 1.0f : xv0 + 1.0f), dz1 = g1 * (xv1 > 0.f ? 1.0f : xv1 + 1.0f);
+                float *dzr = dz_g + (size_t)(r0 + rw) * H3;
+                dzr[lane] = dz0; dzr[lane + 64] = dz1;
+                db0 += dz0; db1 += dz1;
             }
-        }
+        };
+        if (nout == NA) backward(std::true_type{}); else backward(std::false_type{});
+        HSTAMP(4);
     }
-    // the per-row sums of the loss lanes (wave 0), transposed through LDS: lane r writes its 36 partials as column r, thread k then
-    // adds the 64 entries of row k.  (A butterfly of 36 x 6 cross-lane shuffles on one wave took a third of this kernel.)
-    float *ptmp = x + (MA + 1) * NH * H3;                   // behind the [MA + 1][NH][H3] block that `acc` reuses below
-    static_assert((MA + 1) * NH * H3 + (2 * MA + 4) * HEAD_ROWS <= HEAD_ROWS * LDX, "partials fit behind acc in the tile buffer");
+    // Sums over the rows of this workgroup leave through a scratch row, not through atomics: 768 workgroups adding into the
+    // same few dozen addresses serialise in L2 (24 us of the first version's 46 were that queue).  k_head_finish folds the rows.
+    // Column sums: the four waves' partials [MA + 1][NWV][H3] meet in LDS; the loss lanes' row sums (wave 0) are transposed through
+    // LDS (lane r writes its partials as column r, thread k adds the 64 entries of row k).
+    float *acc = buf, *ptmp = buf + (MA + 1) * NWV * H3;
+    static_assert((MA + 1) * NWV * H3 + (2 * MA + 4) * HEAD_ROWS <= NBUF, "sums fit in the tile buffer");
     __syncthreads();                                        // every wave is done with the tile
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+        acc[(a * NWV + wv) * H3 + lane] = a < NA ? dw0[a < NA ? a : 0] : 0.f;
+        acc[(a * NWV + wv) * H3 + lane + 64] = a < NA ? dw1[a < NA ? a : 0] : 0.f;
+    }
+    acc[(MA * NWV + wv) * H3 + lane] = db0;
+    acc[(MA * NWV + wv) * H3 + lane + 64] = db1;
     if (tid < HEAD_ROWS) {
 #pragma unroll
         for (int k = 0; k < 2 * MA + 4; ++k) ptmp[k * HEAD_ROWS + tid] = part[k];
     }
-    // Sums over the rows of this workgroup leave through a scratch row, not through atomics: 768 workgroups adding into the
-    // same few dozen addresses serialise in L2 (24 us of this kernel's 46 were that queue).  k_head_finish folds the rows.
     float *__restrict__ prow = P.head_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * HEAD_PART_STRIDE(H3);
-    float *acc = x;                                         // reuse the tile buffer: [MA + 1][NH][H3]
-    if (half < NH) {
-#pragma unroll
-        for (int a = 0; a < MA; ++a) acc[(a * NH + half) * H3 + c] = dw[a];
-        acc[(MA * NH + half) * H3 + c] = db_prev;
-    }
     __syncthreads();
     if (tid < 2 * MA + 4) {
         float v = 0.f;
-        for (int r = 0; r < HEAD_ROWS; ++r) v += ptmp[tid * HEAD_ROWS + r];
+        for (int rw = 0; rw < HEAD_ROWS; ++rw) v += ptmp[tid * HEAD_ROWS + rw];
         prow[(MA + 1) * H3 + tid] = v;
     }
     for (int i = tid; i < (MA + 1) * H3; i += 256) {
         const int q = i / H3, cc = i % H3;
-        float v = 0.f;
-        for (int h = 0; h < NH; ++h) v += acc[(q * NH + h) * H3 + cc];
-        prow[i] = v;
+        const float *ap = acc + q * NWV * H3 + cc;
+        prow[i] = (ap[0] + ap[H3]) + (ap[2 * H3] + ap[3 * H3]);
     }
+#ifdef LG_HEAD_STAMPS
+    HSTAMP(5);
+    if (tid == 0 && (blockIdx.x % 97) == 0)
+        printf("head wg %d net %d: stage %llu fwd %llu loss %llu bwd %llu sums %llu (x10 ns) start %llu\n", blockIdx.x, blockIdx.y, ts[1] - ts[0], ts[2] - ts[1],
+               ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[0] % 100000ull);
+#endif
 }
 
 // Folds the scratch rows of k_head_net into the gradient buffer: thread = one sum, blockIdx.y = a chunk of the rows,
@@ -1888,7 +1923,10 @@ int ppok_head_fused(const PpoDev *P, int H3, const float *xa, const float *xc, f
     static const int per_net = getenv("LG_HEAD_PER_NET") ? atoi(getenv("LG_HEAD_PER_NET")) : 1;
     if (H3 == 128 && per_net) {
         const int nrows = ntiles < HEAD_NET_GRID ? ntiles : HEAD_NET_GRID;
-        hipLaunchKernelGGL((k_head_net<128>), dim3(nrows, 2), block, 0, s, *P, xa, xc, dza, dzc, w_a, b_a, w_c, b_c, b_prev_a, b_prev_c);
+        if (P->A <= 12)
+            hipLaunchKernelGGL((k_head_net<128, 12>), dim3(nrows, 2), block, 0, s, *P, xa, xc, dza, dzc, P->params + w_a, P->params + w_c, b_a, b_c);
+        else
+            hipLaunchKernelGGL((k_head_net<128, LG_PPO_MAX_A>), dim3(nrows, 2), block, 0, s, *P, xa, xc, dza, dzc, P->params + w_a, P->params + w_c, b_a, b_c);
         constexpr int NTOT = HEAD_PART_STRIDE(128);
         hipLaunchKernelGGL((k_head_finish<128>), dim3((NTOT + 255) / 256, HEAD_FIN_CHUNKS, 2), block, 0, s, *P, nrows, w_a, b_a, w_c, b_c,
                            b_prev_a, b_prev_c);
