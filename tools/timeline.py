@@ -3,7 +3,7 @@
 import csv, glob, os, sys
 
 d = sys.argv[1]
-f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)   # gpurun merges: older collections may lie beside
 trace = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in trace]
 
