@@ -10,9 +10,11 @@
 // 6x6 product, a rank-one update and a spatial dot product are role-free code:
 //      (I x).mine = mm * x.mine + mo * x.other          x.other = DPP quad_perm [1,0,3,2] of x.mine
 //      <a, b>     = dot3(a.mine, b.mine) + the partner's (one DPP add)
-// Only the spatial cross products and the rigid-body inertia need a role select.  3x3 kinematics, contact detection and
-// the scalar contact law run redundantly in both lanes (identical inputs, identical results), so every branch and trip
-// count stays uniform inside a pair.  Lanes of an environment: index = leg * 2 + h, i.e. 2L consecutive lanes; leg sums
+// Only the spatial cross products and the rigid-body inertia need a role select.  The 3x3 kinematics run redundantly in both
+// lanes (identical inputs, identical results).  Scalar work per collision sphere does not (round 4): contact detection and the
+// contact law of the sweeps are DEALT between the two lanes -- lane h detects slots 2i + h and takes every other active contact of
+// the leg through the sweeps, the halves of the link velocity and of the impulse swapped by DPP -- because a launch lasts as long
+// as its workgroup with the most contacts per leg (profiles/r04_substeps_spread.txt).  Lanes of an environment: index = leg * 2 + h, i.e. 2L consecutive lanes; leg sums
 // are DPP butterflies over lane xor 2 (and xor 4 for L = 4).  A block's 64 (env, leg) pairs occupy waves 0 and 1, which
 // sit on different SIMDs of the CU and run concurrently.
 #pragma once
