@@ -299,8 +299,10 @@ __device__ __forceinline__ int physics_pair(const PhysCfg &c /* phys_cfg(P): reg
     }
 
     PSTAMP(pr, 5);
-    // ---- contact detection + W per slot.  The records are shared by the pair: both lanes compute and store the same
-    // values to the same column (each lane reads back what it wrote itself; no cross-lane ordering is relied on).
+    // ---- contact detection + W per slot.  The records are shared by the pair in one LDS column, and since round 4 a lane reads records
+    // its PARTNER wrote (detection and the sweeps' contact law are dealt between the lanes; W and the force output read every record):
+    // both lanes are lanes of one wave, whose LDS instructions execute in program order, and a record's address is computed alike in
+    // both, so the compiler keeps write -> read order as well.
     const float mu = 0.5f * (friction + c.ground_friction);
     // Detection is scalar work per sphere, so the pair does not share it either: lane h takes slots 2i + h (the table rows of the leg's
     // spheres and of the base spheres dealt to this leg are contiguous, LG_LT_SLOTS + 4 si), two passes, both written out -- the first
