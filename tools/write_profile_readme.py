@@ -31,8 +31,13 @@ Workload: anymal_c_flat, 4096 envs, ActorCritic [512,256,128] (BASELINE.json con
 | `{tag}_pmc_traffic.json` | HBM bytes per minibatch GEMM group / per `lg_step` call, read by bench.py as `roofline.traffic` |
 | `{tag}_timelines.txt` | kernel-trace timeline of one minibatch and of one policy step |
 | `{tag}_gpu_tests.log` | `pytest -m gpu` on the same box ({tests.strip('= ')}) |
-| `{tag}_learning_curve.md` | learning sanity runs (ANYmal-C and A1 learn to walk in 5-6 s of wall time) |
-| `{tag}_other_configs.md` | env-steps/s of the rough-terrain and Cassie configurations |
+| `{tag}_learn_*.log` | learning sanity runs on the round's final physics (flat walk, rough terrain curriculum, trajectory task with the authors' staged curriculum, Cassie) |
+| `{tag}_anymal_c_rough_*`, `{tag}_cassie_*` | the same kernel table / timelines / PMC traffic for BASELINE configs[2] and configs[4] |
+| `{tag}_env_step_time.txt`, `{tag}_substeps_sections.txt`, `{tag}_substeps_clock.json`, `{tag}_substeps_pmc.json`, `{tag}_post_step_phases.txt` | `lg_step` and its stages by HIP events; section clocks, in-kernel clock and SQ instruction counts of the control loop; phase clocks of the post-step |
+| `{tag}_substeps_spread.txt` | every control-loop workgroup's life on the chip-wide clock, sections of the fastest / slowest workgroup, before and after the round's control-loop work (DESIGN.md §0 item 4) |
+| `{tag}_ab.txt` | alternating A/B runs of the round (what was kept, what was measured and dropped) |
+| `{tag}_gemm_glds_proto.txt`, `{tag}_gemm_power.txt`, `{tag}_gemm_clock.txt` | the LDS-DMA GEMM prototype's 25 variants, the workgroup-count sweep by kernel trace, in-kernel clocks of the GEMM kernels |
+| `{tag}_diag_faults.txt` | what tripped round 3's physics guard, and the same run after the fix |
 
 ## Kernel table (3 timed + 1 warm-up iterations, + the roofline probes of bench.py)
 
