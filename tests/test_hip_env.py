@@ -115,6 +115,50 @@ def test_physics_substep_matches_oracle(name, z0, oracle_built):
         ora.close()
 
 
+@pytest.mark.parametrize("name,min_bodies", [("anymal_c_flat", 7), ("anymal_c_rough", 7), ("cassie", 3)])
+def test_fallen_robots_match_oracle(name, min_bodies, oracle_built):
+    """Robots lying on the ground in every orientation (on their side, on their back): thighs, shanks, feet and base spheres all
+    touch, three to eight contacts per leg.  That is the path that sets a control-loop launch's duration (profiles/r04_substeps_spread.txt)
+    and the one the round-4 kernel changed most: active contacts dealt between the two lanes of a pair, the first ones in registers
+    and the rest through the pair's LDS column, W from the inward pass alone -- against the oracle's literal loops.  Glued after every
+    substep; the contact-force band of test_physics_substep_matches_oracle, and the legs must really be loaded with contacts."""
+    hip, ora, z, meta = _pair(name, oracle_built, n=256)
+    try:
+        rng = np.random.default_rng(17)
+        n, A = 256, meta["num_dofs"]
+        origins = z["const_env_origins_init"][rng.integers(0, len(z["const_env_origins_init"]), n)] if meta["custom_origins"] else None
+        _seed_state([hip, ora], rng, n, A, 0.10, origins)
+        root = ora.get("root_states").copy()
+        q = rng.normal(size=(n, 4)).astype(np.float32)                     # any orientation
+        root[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        root[:, 2] += 0.12                                                 # base centre a sphere radius or two above the surface
+        root[:, 7:13] *= 0.2
+        for e in (hip, ora):
+            e.set("root_states", root)
+        tau = rng.uniform(-10, 10, (n, A)).astype(np.float32)
+        most = 0
+        for step in range(8):
+            for e in (hip, ora):
+                e.set("torques", tau)
+                e.call("simulate")
+            cf_h, cf_o = hip.get("contact_forces"), ora.get("contact_forces")
+            most = max(most, int((np.abs(cf_o).sum(-1) > 0).sum(1).max()))
+            assert np.isfinite(hip.get("root_states")).all() and np.isfinite(hip.get("dof_state")).all()
+            np.testing.assert_allclose(hip.get("root_states"), ora.get("root_states"), rtol=5e-4, atol=5e-4)
+            dh, do = hip.get("dof_state").astype(np.float64), ora.get("dof_state").astype(np.float64)
+            err = np.abs(dh - do)
+            assert (err[..., 0] <= 5e-4 + 5e-4 * np.abs(do[..., 0])).all(), err[..., 0].max()
+            assert (err[..., 1] <= 5e-3 + 5e-3 * np.abs(do[..., 1])).mean() > 0.998, float(err[..., 1].max())
+            np.testing.assert_allclose(cf_h, cf_o, rtol=5e-3, atol=1.0)
+            hip.set("root_states", ora.get("root_states"))
+            hip.set("dof_state", ora.get("dof_state"))
+        # (the biped's collision model has fewer bodies: three at once is everything it can put on the ground)
+        assert most >= min_bodies, f"no env with many bodies in contact ({most}): the test never left the one-contact-per-leg path"
+    finally:
+        hip.close()
+        ora.close()
+
+
 @pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie", "a1", "anymal_b"])
 def test_full_step_philox_matches_oracle(name, oracle_built):
     """lg_step with the built-in Philox streams (no injection) vs the oracle on the same seed:
