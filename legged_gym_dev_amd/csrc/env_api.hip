@@ -340,6 +340,8 @@ int lg_debug_control_loop(lg_ctx *c, const float *actions) { return run_substeps
 static int g_fused_substeps = 1;
 int lg_debug_set_fused(int v) { g_fused_substeps = v; return 0; }
 extern "C" void lgk_debug_set_substeps_nw(int v);
+extern "C" void lgk_debug_set_substeps_occ(int v);
+int lg_debug_set_substeps_occ(int v) { lgk_debug_set_substeps_occ(v); return 0; }     // control-loop register budget: 0 by grid size, 1 / 2 forced
 int lg_debug_set_substeps_nw(int v) { lgk_debug_set_substeps_nw(v); return 0; }   // control-loop block shape: 4 waves / 64/L envs, or 2 / 32/L
 extern "C" void lgk_debug_set_phys_pair(int v);
 int lg_debug_set_phys_pair(int v) { lgk_debug_set_phys_pair(v); return 0; }   // physics lane map: 1 pair-lane (default), 0 one lane per leg

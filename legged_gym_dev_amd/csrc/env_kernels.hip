@@ -117,8 +117,11 @@ __device__ __forceinline__ void lstm8_rows(const float *__restrict__ wr, int k, 
 // per CU that larger env counts use.
 #define LG_RUN_TORQUES 1
 #define LG_RUN_PHYSICS 2
-template <int L, int J, bool LSTM, bool PAIR, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, 1) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
+// OCC = waves per SIMD the kernel is compiled for.  1: the whole register file (292 VGPRs for the quadruped), the shape every launch of up
+// to one workgroup per CU takes; 2: 256 VGPRs (152 B of scratch), so that two workgroups of a larger env count share a CU instead of
+// running one after the other (8192 envs: 110 us against 143; at 4096 the spills cost 6 %: profiles/r04_env_count_sweep.txt).
+template <int L, int J, bool LSTM, bool PAIR, int NW = 4, int OCC = 1>
+__global__ void __launch_bounds__(64 * NW, OCC) k_substeps(const DevParams *__restrict__ P, const float *__restrict__ a_in, int mode, int iters) {
     // NW waves per block.  NW = 4: two physics waves (pair-lane map) + two that only run the actuator net, 64/L envs.  NW = 2 (pair-lane
     // map only): one physics wave + one actuator-net wave, 32/L envs -- two such blocks per CU, and no physics wave ever waits at a
     // substep barrier for the other one's contacts (LG_SUBSTEPS_NW).
@@ -1105,6 +1108,8 @@ static int phys_pair_enabled() {
 // nothing, the chain per wave is the same); biped 148.7 (4: 128 blocks, half the CUs idle) vs 145.5 us (2: 256 blocks).  Results are
 // bit-identical either way (tests/test_hip_env.py::test_control_loop_block_shapes_are_bit_identical).
 static int g_substeps_nw = -1;
+static int g_substeps_occ = 0;        // 0: by grid size; 1 / 2: force the build for that many waves per SIMD (tests)
+extern "C" void lgk_debug_set_substeps_occ(int v) { g_substeps_occ = v == 1 || v == 2 ? v : 0; }
 extern "C" void lgk_debug_set_substeps_nw(int v) { g_substeps_nw = v == 2 ? 2 : v == 4 ? 4 : 0; }
 template <int L, int J, bool LSTM>
 static void launch_substeps(int N, const DevParams *P, const float *a_in, int mode, int iters, hipStream_t s) {
@@ -1113,8 +1118,15 @@ static void launch_substeps(int N, const DevParams *P, const float *a_in, int mo
     const int nw = g_substeps_nw ? g_substeps_nw : (L == 2 ? 2 : 4);
     if (phys_pair_enabled() && nw == 2)
         hipLaunchKernelGGL((k_substeps<L, J, LSTM, true, 2>), dim3((N + epw2 - 1) / epw2), dim3(128), 0, s, P, a_in, mode, iters);
-    else if (phys_pair_enabled())
-        hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3((N + epw4 - 1) / epw4), dim3(256), 0, s, P, a_in, mode, iters);
+    else if (phys_pair_enabled()) {
+        static int cus = 0;
+        if (!cus) { int dev = 0; hipDeviceProp_t pr; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+        const int grid = (N + epw4 - 1) / epw4;
+        if (L == 4 && (g_substeps_occ ? g_substeps_occ == 2 : grid > cus))   // more workgroups than CUs: the 256-register build, two per CU (bit-identical results)
+            hipLaunchKernelGGL((k_substeps<L, J, LSTM, true, 4, (L == 4 ? 2 : 1)>), dim3(grid), dim3(256), 0, s, P, a_in, mode, iters);
+        else
+            hipLaunchKernelGGL((k_substeps<L, J, LSTM, true>), dim3(grid), dim3(256), 0, s, P, a_in, mode, iters);
+    }
     else hipLaunchKernelGGL((k_substeps<L, J, LSTM, false>), dim3((N + epw4 - 1) / epw4), dim3(256), 0, s, P, a_in, mode, iters);
 }
 extern "C" int lgk_substeps(const DevParams *P, const float *a_in, int N, int L, int J, int lstm, int mode, int iters, hipStream_t s) {

@@ -294,11 +294,14 @@ def test_fused_control_loop_equals_launch_per_substep(name):
         b.close()
 
 
+@pytest.mark.parametrize("shape", ["two_waves", "two_per_cu"])
 @pytest.mark.parametrize("name", ["anymal_c_flat", "anymal_c_rough", "cassie"])
-def test_control_loop_block_shapes_are_bit_identical(name):
+def test_control_loop_block_shapes_are_bit_identical(name, shape):
     """The control loop on blocks of 4 waves (two physics waves, 64/L envs) against blocks of 2 waves (one physics wave, 32/L envs:
     LG_SUBSTEPS_NW=2): which workgroup an environment lands in and how many waves share its barriers must not change a bit of
-    its state -- 133 envs (ragged last block in both shapes), 6 policy steps with contacts and resets."""
+    its state -- 133 envs (ragged last block in both shapes), 6 policy steps with contacts and resets.  "two_per_cu": the same
+    4-wave kernel compiled for two waves per SIMD (256 registers, some of its state in scratch), which launches of more workgroups
+    than CUs take (above 4096 quadruped envs per GPU): register allocation must not change a bit either."""
     z, meta = harness.load_fixture(name)
     n = 133
     cfg = harness.make_cfg(name)
@@ -324,14 +327,19 @@ def test_control_loop_block_shapes_are_bit_identical(name):
         for t in range(6):
             act = rng.uniform(-3, 3, (n, A)).astype(np.float32)
             lib.lg_debug_set_substeps_nw(4)
+            lib.lg_debug_set_substeps_occ(1)
             a.step(act)
-            lib.lg_debug_set_substeps_nw(2)
+            if shape == "two_waves":
+                lib.lg_debug_set_substeps_nw(2)
+            else:
+                lib.lg_debug_set_substeps_occ(2)
             b.step(act)
             for key in ("reset", "episode_length", "torques", "dof_state", "root_states", "obs", "rew", "lstm_h", "lstm_c",
                         "contact_forces", "feet_air_time"):
                 np.testing.assert_array_equal(a.get(key), b.get(key), err_msg=f"step {t} {key}")
     finally:
         lib.lg_debug_set_substeps_nw(0)                            # back to the default: by topology
+        lib.lg_debug_set_substeps_occ(0)                           # ... and by grid size
         a.close()
         b.close()
 
