@@ -35,6 +35,7 @@ Workload: anymal_c_flat, 4096 envs, ActorCritic [512,256,128] (BASELINE.json con
 | `{tag}_anymal_c_rough_*`, `{tag}_cassie_*` | the same kernel table / timelines / PMC traffic for BASELINE configs[2] and configs[4] |
 | `{tag}_env_step_time.txt`, `{tag}_substeps_sections.txt`, `{tag}_substeps_clock.json`, `{tag}_substeps_pmc.json`, `{tag}_post_step_phases.txt` | `lg_step` and its stages by HIP events; section clocks, in-kernel clock and SQ instruction counts of the control loop; phase clocks of the post-step |
 | `{tag}_substeps_spread.txt` | every control-loop workgroup's life on the chip-wide clock, sections of the fastest / slowest workgroup, before and after the round's control-loop work (DESIGN.md §0 item 4) |
+| `{tag}_env_count_sweep.txt` | env-steps/s and control-loop time against the env count on one GPU (1024 … 32768) |
 | `{tag}_ab.txt` | alternating A/B runs of the round (what was kept, what was measured and dropped) |
 | `{tag}_gemm_glds_proto.txt`, `{tag}_gemm_power.txt`, `{tag}_gemm_clock.txt` | the LDS-DMA GEMM prototype's 25 variants, the workgroup-count sweep by kernel trace, in-kernel clocks of the GEMM kernels |
 | `{tag}_diag_faults.txt` | what tripped round 3's physics guard, and the same run after the fix |
